@@ -1,0 +1,137 @@
+/*
+ * upmix_hip.h - C ABI of libupmix_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the multi-band STFT centre-extraction hot path of
+ * willleskowitz/upmix.  The reference has no FFI; its boundary for this path
+ * is the Python call
+ *     extract_center_left_right_multi_band_in_memory(L, R, sr, band_extractors)
+ *         -> (center, left, right)          python-prototype/center_extraction.py:477-513
+ * which fans out MultiBandExtractorAccu.process_all_blocks(L, R) per band
+ * (center_extraction.py:426-472, hot loop :449-460 -> process_stereo_chunk :353-409)
+ * and sums the bands in float32 (:503-511).  Everything that function computes
+ * from (L, R, band parameters) is what upx_process() computes.  Band planning,
+ * window design and the band-limit gain vector stay on the host and cross this
+ * ABI as DATA (float arrays), exactly as the reference precomputes them in
+ * MultiBandExtractorAccu.__init__ (:240-271) and _band_limit (:334-351).
+ *
+ * Plain C: pointers + sizes, no C++/torch/numpy types.  All functions return 0
+ * on success or a negative upx_status; upx_last_error() gives the message of
+ * the last failure on the calling thread.  A plan is not thread-safe; distinct
+ * plans are.
+ */
+#ifndef UPMIX_HIP_H
+#define UPMIX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum upx_status {
+    UPX_OK = 0,
+    UPX_ERR_INVALID = -1,     /* bad argument (maps to ValueError on the Python side) */
+    UPX_ERR_UNSUPPORTED = -2, /* STFT size / overlap not covered by the kernels */
+    UPX_ERR_HIP = -3,         /* HIP runtime failure */
+    UPX_ERR_NO_DEVICE = -4,   /* no usable GPU */
+    UPX_ERR_RCCL = -5,        /* RCCL missing or failed */
+    UPX_ERR_NOMEM = -6
+} upx_status;
+
+typedef struct upx_plan upx_plan;
+typedef struct upx_comm upx_comm;
+
+/* ABI version of this header (bumped on incompatible change). */
+int upx_abi_version(void);
+
+/* Message of the last error on this thread ("" if none). */
+const char* upx_last_error(void);
+
+/* Number of visible HIP devices. */
+int upx_device_count(int* count);
+
+/* 1 if (block_size, hop) is covered by the gfx950 kernels, else 0. */
+int upx_supported(int32_t block_size, int32_t hop);
+
+/*
+ * Create a plan for n_bands bands on `device`.
+ *   block_size[b], hop[b]      STFT size N_b and hop (center_extraction.py:250-252)
+ *   w_analysis  = concat_b analysis_window[N_b]      float32 (:257)
+ *   w_synthesis = concat_b synthesis_window[N_b]     float32 (:258, design :80-105)
+ *   gain        = concat_b g_b[N_b/2+1]              float32: the real per-bin factor
+ *                 _band_limit applies to both spectra (:334-351)
+ * Arrays are copied; nothing is retained.  Replaces the per-band state built by
+ * chain_bands (:518-580) / MultiBandExtractorAccu.__init__ (:240-271).
+ */
+int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* block_size, const int32_t* hop,
+                    const float* w_analysis, const float* w_synthesis, const float* gain);
+void upx_plan_destroy(upx_plan* plan);
+
+/* Tuning: hop-blocks each stream walks (0 = automatic).  band = -1 sets all bands. */
+int upx_plan_set_blocks_per_stream(upx_plan* plan, int band, int blocks);
+
+/*
+ * Whole-signal call on HOST buffers (H2D, kernels, D2H; blocking).
+ *   stereo  interleaved float32 [T][2] (L, R)
+ *   out_c/out_l/out_r  float32 [T] each: centre, left-side, right-side
+ * Replaces extract_center_left_right_multi_band_in_memory (:477-513); same
+ * (center, left, right) order.
+ */
+int upx_process(upx_plan* plan, const float* stereo, int64_t n_samples, float* out_c, float* out_l, float* out_r);
+
+/* ---- device-resident interface (benchmarks, sharding, pipelines) -------- */
+int upx_dev_alloc(upx_plan* plan, void** ptr, size_t bytes);
+int upx_dev_free(upx_plan* plan, void* ptr);
+int upx_dev_memset(upx_plan* plan, void* ptr, int value, size_t bytes);
+int upx_copy_h2d(upx_plan* plan, void* dst_dev, const void* src_host, size_t bytes);
+int upx_copy_d2h(upx_plan* plan, void* dst_host, const void* src_dev, size_t bytes);
+int upx_sync(upx_plan* plan);
+
+/*
+ * Run all bands on device buffers (asynchronous on the plan's stream).
+ *   d_stereo  [t_in][2]  valid input samples from local sample 0 (zero beyond)
+ *   own_len   samples this call owns: frames j with j*hop_b < own_len are computed
+ *   t_out     length of the output planes; hop-blocks up to
+ *             min(t_out, own_len + N_b - hop_b) receive band b (the part beyond
+ *             own_len is the overlap-add spill used for multi-GPU seams)
+ * For a whole signal: t_in = own_len = t_out = T.
+ */
+int upx_process_device(upx_plan* plan, const float* d_stereo, int64_t t_in, int64_t own_len, float* d_c,
+                       float* d_l, float* d_r, int64_t t_out);
+
+/* Per-band kernel timing with HIP events on the plan's stream. */
+int upx_plan_enable_timing(upx_plan* plan, int enable);
+/* Milliseconds of each band's kernel in the last upx_process_device call (syncs). */
+int upx_plan_band_times_ms(upx_plan* plan, float* ms, int n_bands);
+/* Kernel symbol name / launch geometry of a band (for profiles and DESIGN.md). */
+int upx_plan_band_info(upx_plan* plan, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,
+                       int32_t* blocks_per_stream);
+
+/* max|x| over n floats on the device (peak normalisation of main.py:85-88). */
+int upx_absmax(upx_plan* plan, const float* d_x, int64_t n, float* result);
+/* x *= scale on the device (main.py:95-97). */
+int upx_scale(upx_plan* plan, float* d_x, int64_t n, float scale);
+
+/* ---- multi-GPU seam exchange over RCCL (one process per GPU) ------------ */
+#define UPX_UNIQUE_ID_BYTES 128
+/* Rank 0 creates the id and shares the 128 bytes with the other ranks out of band. */
+int upx_comm_unique_id(char* id_out);
+int upx_comm_create(upx_comm** out, upx_plan* plan, int rank, int n_ranks, const char* id);
+void upx_comm_destroy(upx_comm* comm);
+/*
+ * Overlap-add seam: each rank's planes hold `spill` samples past own_len that
+ * belong to the next rank's head.  Packs them into seam[n_ranks][3][spill],
+ * one ncclAllReduce(sum, float32), adds row rank-1 onto the head of this rank.
+ * own_len == 0 ranks are not supported.
+ */
+int upx_comm_seam_exchange(upx_comm* comm, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill);
+/* Same seam arithmetic between two shards on ONE device (no RCCL): adds the
+   spill of the `prev` planes onto the head of the `next` planes. */
+int upx_seam_add_local(upx_plan* plan, const float* prev_c, const float* prev_l, const float* prev_r,
+                       int64_t prev_own_len, float* next_c, float* next_l, float* next_r, int64_t spill);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UPMIX_HIP_H */

@@ -1,0 +1,66 @@
+// TEST INFRASTRUCTURE ONLY.  Host build (g++) of upmix_amd/csrc/upx_core.h with a
+// sequential executor: every `each` phase runs for all threads of the workgroup
+// before the next phase starts, which is exactly the barrier semantics of the
+// gfx950 kernel.  Lets tests/test_emulator.py check the kernel's indexing, LDS
+// layout and framing logic against the oracle without a GPU.  The product
+// (upmix_amd) never loads this library.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../upmix_amd/csrc/upx_core.h"
+
+namespace {
+struct SeqExec {
+    std::vector<upx::Thread> st;
+    template <class F>
+    void each(F&& f) {
+        for (size_t t = 0; t < st.size(); ++t) f((int)t, st[t]);
+    }
+};
+
+void turn_trig(double frac, double& c, double& s) {
+    const double a = 2.0 * M_PI * frac;
+    c = std::cos(a);
+    s = std::sin(a);
+}
+
+template <class C>
+int run(upx::BandArgs a) {
+    std::vector<upx::cf> tw((size_t)(C::TW_ROWS > 0 ? C::TW_ROWS : 1) * C::LANES);
+    upx::fill_twiddles<C>(tw.data(), turn_trig);
+    a.tw = tw.data();
+    const long long n_blocks = (long long)a.m_hi - a.m_lo;
+    if (n_blocks <= 0) return 0;
+    const long long n_streams = (n_blocks + a.blocks_per_stream - 1) / a.blocks_per_stream;
+    const long long n_wg = (n_streams + C::G - 1) / C::G;
+    std::vector<upx::cf> lds((size_t)C::G * C::PITCH);
+    for (long long wg = 0; wg < n_wg; ++wg) {
+        SeqExec ex;
+        ex.st.resize(C::WG);
+        // poison LDS so that reads of never-written cells are visible
+        for (auto& v : lds) v = upx::mk(NAN, NAN);
+        upx::band_program<C>(ex, a, lds.data(), (int)wg);
+    }
+    return 0;
+}
+}   // namespace
+
+extern "C" int emu_band(int log2n, int k_overlap, const float* in, long long t_in, float* out_c, float* out_l,
+                        float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
+                        const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int blocks_per_stream,
+                        int accumulate) {
+    upx::BandArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const upx::cf*>(in);
+    a.out_c = out_c; a.out_l = out_l; a.out_r = out_r;
+    a.w_a = w_a; a.w_s = w_s_scaled; a.gain = gain_half;
+    a.t_in = (int)t_in; a.t_out = (int)t_out;
+    a.j_lo = j_lo; a.j_hi = j_hi; a.m_lo = m_lo; a.m_hi = m_hi;
+    a.blocks_per_stream = blocks_per_stream; a.accumulate = accumulate;
+#define UPX_CASE(L, K) if (log2n == L && k_overlap == K) return run<upx::Cfg<L, K>>(a);
+    UPX_CASE(8, 4) UPX_CASE(9, 4) UPX_CASE(10, 4) UPX_CASE(11, 4) UPX_CASE(12, 4) UPX_CASE(13, 4)
+    UPX_CASE(8, 2) UPX_CASE(10, 2) UPX_CASE(10, 8) UPX_CASE(12, 8) UPX_CASE(13, 2)
+#undef UPX_CASE
+    return -1;
+}

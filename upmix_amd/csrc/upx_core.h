@@ -1,0 +1,585 @@
+// upx_core.h - per-band WOLA STFT centre-extraction stream for gfx950 (CDNA4).
+//
+// One *stream* = N/16 lanes that walk consecutive STFT frames of one band and
+// keep the overlap-add state of Ls/C/Rs in registers.  Per frame:
+//   load interleaved stereo (L + iR is the complex FFT input) * w_A
+//   -> complex FFT_N (Stockham, radix-16 passes through LDS, 16 points/lane)
+//   -> split L/R spectra, band gain, per-bin coherence/balance mask
+//   -> iFFT_N of (Ls + i Rs); iFFT_N of (C_a + i C_b) once per frame PAIR
+//   -> * w_S, overlap-add in registers, emit one hop, shift.
+// That is 5 complex FFTs per 2 frames for the reference's 10 real transforms
+// (center_extraction.py:366-367 forward, :387-389 inverse), the mask of
+// :373-384, the band limiter of :334-351 as a precomputed gain vector, and
+// the overlap-add of :392-407 / framing of :426-472 in closed form
+// (SURVEY.md section 3.3).
+//
+// The body is written against an executor `Ex` whose `each(f)` runs `f` for
+// every thread of the workgroup and then barriers.  On the GPU that is the
+// thread itself + s_barrier; tests/emu instantiates the SAME code with a
+// sequential executor on the host to check indexing without a GPU (test
+// infrastructure only - nothing in the product path runs on the CPU).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define UPX_HD __host__ __device__ __forceinline__
+#else
+#define UPX_HD inline
+#endif
+
+namespace upx {
+
+struct cf {
+    float x, y;
+};
+
+UPX_HD cf mk(float a, float b) { cf r; r.x = a; r.y = b; return r; }
+UPX_HD cf operator+(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+UPX_HD cf operator-(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+UPX_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+UPX_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }   // a * (-i)
+UPX_HD cf cswap(cf a) { return mk(a.y, a.x); }
+
+UPX_HD float fast_rcp(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(v);
+#else
+    return 1.0f / v;
+#endif
+}
+UPX_HD float fast_sqrt(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(v);
+#else
+    return __builtin_sqrtf(v);
+#endif
+}
+
+// Per-thread table values (twiddles, windows, gains) are the same every frame, so
+// the optimiser would hoist ~120 registers of loads out of the frame loop.  Passing
+// the table pointer through an empty asm per phase keeps the loads inside the loop
+// (they hit L1/L2) and the state in registers small.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UPX_GLOBAL __attribute__((address_space(1)))
+#else
+#define UPX_GLOBAL
+#endif
+template <class T>
+UPX_HD const UPX_GLOBAL T* opaque(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(p));
+    return (const UPX_GLOBAL T*)p;   // tables live in global memory: global_load, not flat_load
+#else
+    return p;
+#endif
+}
+// Stops the instruction scheduler from interleaving independent unrolled
+// iterations across this point (it otherwise trades ~130 extra VGPRs for ILP).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UPX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define UPX_SCHED_FENCE() ((void)0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T>
+UPX_HD const UPX_GLOBAL T* opaque(const UPX_GLOBAL T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+template <class T>
+UPX_HD UPX_GLOBAL T* opaque(UPX_GLOBAL T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+#endif
+template <class T>
+UPX_HD UPX_GLOBAL T* opaque(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(p));
+#endif
+    return (UPX_GLOBAL T*)p;
+}
+
+// ---------------------------------------------------------------------------
+// Register DFTs, forward sign exp(-2 pi i nk/R), natural-order in and out.
+// ---------------------------------------------------------------------------
+constexpr float kSqrtHalf = 0.70710678118654752440f;
+constexpr float kC16 = 0.92387953251128675613f;   // cos(pi/8)
+constexpr float kS16 = 0.38268343236508977173f;   // sin(pi/8)
+
+UPX_HD void dft2(cf& a, cf& b) {
+    cf t = a - b;
+    a = a + b;
+    b = t;
+}
+
+UPX_HD void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
+    cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = t1 + t3;
+    a3 = t1 - t3;
+}
+
+// multiply by W8^1 = (1 - i)/sqrt2 and W8^3 = (-1 - i)/sqrt2
+UPX_HD cf mul_w8_1(cf a) { return mk((a.x + a.y) * kSqrtHalf, (a.y - a.x) * kSqrtHalf); }
+UPX_HD cf mul_w8_3(cf a) { return mk((a.y - a.x) * kSqrtHalf, -(a.x + a.y) * kSqrtHalf); }
+
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<2> {
+    static UPX_HD void run(cf* v) { dft2(v[0], v[1]); }
+};
+template <>
+struct Dft<4> {
+    static UPX_HD void run(cf* v) { dft4(v[0], v[1], v[2], v[3]); }
+};
+template <>
+struct Dft<8> {
+    // n = 2a + b: two DFT4 over a, twiddle W8^(b k1), DFT2 over b
+    static UPX_HD void run(cf* v) {
+        cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+        cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+        dft4(e0, e1, e2, e3);
+        dft4(o0, o1, o2, o3);
+        o1 = mul_w8_1(o1);
+        o2 = mul_mi(o2);
+        o3 = mul_w8_3(o3);
+        v[0] = e0 + o0; v[4] = e0 - o0;
+        v[1] = e1 + o1; v[5] = e1 - o1;
+        v[2] = e2 + o2; v[6] = e2 - o2;
+        v[3] = e3 + o3; v[7] = e3 - o3;
+    }
+};
+template <>
+struct Dft<16> {
+    // n = 4a + b, k = k1 + 4 k2:  X[k1+4k2] = DFT4_b( W16^(b k1) * DFT4_a(v[4a+b])[k1] )[k2]
+    static UPX_HD void run(cf* v) {
+        cf y[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            y[b][0] = v[b]; y[b][1] = v[4 + b]; y[b][2] = v[8 + b]; y[b][3] = v[12 + b];
+            dft4(y[b][0], y[b][1], y[b][2], y[b][3]);
+        }
+        const cf w1 = mk(kC16, -kS16), w3 = mk(kS16, -kC16);
+        y[1][1] = cmul(y[1][1], w1);
+        y[1][2] = mul_w8_1(y[1][2]);
+        y[1][3] = cmul(y[1][3], w3);
+        y[2][1] = mul_w8_1(y[2][1]);
+        y[2][2] = mul_mi(y[2][2]);
+        y[2][3] = mul_w8_3(y[2][3]);
+        y[3][1] = cmul(y[3][1], w3);
+        y[3][2] = mul_w8_3(y[3][2]);
+        y[3][3] = cmul(y[3][3], mk(-kC16, kS16));   // W16^9 = -W16^1
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            dft4(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
+            v[k1] = y[0][k1]; v[k1 + 4] = y[1][k1]; v[k1 + 8] = y[2][k1]; v[k1 + 12] = y[3][k1];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// Static configuration per (log2 N, K = frames overlapping one sample)
+// ---------------------------------------------------------------------------
+constexpr int kP = 16;   // complex points per lane
+
+template <int LOG2N>
+struct Passes;   // radix schedule, product = N, first radix 16
+template <> struct Passes<8>  { static constexpr int n = 2; static constexpr int r[4] = {16, 16, 1, 1}; };
+template <> struct Passes<9>  { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 2, 1}; };
+template <> struct Passes<10> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 4, 1}; };
+template <> struct Passes<11> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 8, 1}; };
+template <> struct Passes<12> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 16, 1}; };
+template <> struct Passes<13> { static constexpr int n = 4; static constexpr int r[4] = {16, 16, 16, 2}; };
+
+constexpr int pass_ns(const int* r, int p) { return p == 0 ? 1 : r[p - 1] * pass_ns(r, p - 1); }
+// twiddle rows (each LANES entries) before pass p: sum over earlier twiddled passes of (P/R)*(R-1)
+constexpr int tw_rows_before(const int* r, int p) {
+    return p <= 1 ? 0 : (kP / r[p - 1]) * (r[p - 1] - 1) + tw_rows_before(r, p - 1);
+}
+
+template <int LOG2N_, int K_>
+struct Cfg {
+    static constexpr int LOG2N = LOG2N_;
+    static constexpr int N = 1 << LOG2N_;
+    static constexpr int K = K_;                         // hop = N / K
+    static constexpr int HOP = N / K_;
+    static constexpr int LANES = N / kP;                 // lanes per stream
+    static constexpr int WG = LANES < 256 ? 256 : LANES; // threads per workgroup
+    static constexpr int G = WG / LANES;                 // streams per workgroup
+    static constexpr int HS = kP / K_;                   // register slots per hop
+    static constexpr int SPITCH = LANES + LANES / 16;    // padded distance of one slot step
+    static constexpr int PITCH = N + N / 16 + 16;        // padded complex per stream buffer (+1 row: index N is addressable)
+    using PS = Passes<LOG2N_>;
+    static constexpr int TW_ROWS = tw_rows_before(PS::r, PS::n);
+    static_assert(K_ == 2 || K_ == 4 || K_ == 8 || K_ == 16, "hop must be N/2, N/4, N/8 or N/16");
+};
+
+// LDS index padding: one spare complex after every 16, so that the stride-16
+// scatter of the first Stockham pass (lane j writes 16 j + r) spreads over all
+// banks.  pad16(a + b) == pad16(a) + b + b/16 whenever b is a multiple of 16.
+UPX_HD int pad16(int i) { return i + (i >> 4); }
+
+// ---------------------------------------------------------------------------
+// Kernel arguments (one band, one launch).  Sample counts per launch are
+// limited to 2^29 so that byte offsets fit 32 bits; the host shards longer
+// signals (the same seam arithmetic as the multi-GPU path).
+// ---------------------------------------------------------------------------
+struct BandArgs {
+    const cf* in;          // interleaved stereo, local sample 0; (L,R) is read as L + iR
+    float* out_c;          // planar outputs, local sample 0
+    float* out_l;
+    float* out_r;
+    const float* w_a;      // analysis window [N]
+    const float* w_s;      // synthesis window / N [N]
+    const float* gain;     // 0.5 * band-limit gain [N/2+1]
+    const cf* tw;          // inter-pass twiddles, [row][LANES]
+    int t_in;              // valid input samples  [0, t_in)
+    int t_out;             // valid output samples [0, t_out)
+    int j_lo, j_hi;        // frames that exist: j in [j_lo, j_hi), frame j starts at j*hop
+    int m_lo, m_hi;        // hop-blocks to emit: m in [m_lo, m_hi)
+    int blocks_per_stream; // F
+    int accumulate;        // 0: out = band, 1: out += band (band sum in list order)
+};
+
+constexpr float kEps = 1e-12f;   // center_extraction.py:36
+
+// coherence * (1 - |balance|) mask of center_extraction.py:373-384 on one bin.
+// |L conj(R)| is evaluated as |L||R| (identical in exact arithmetic).
+UPX_HD void mask_bin(cf l, cf r, cf& c, cf& ls, cf& rs) {
+    float ml = fast_sqrt(l.x * l.x + l.y * l.y);
+    float mr = fast_sqrt(r.x * r.x + r.y * r.y);
+    float p = ml * mr;
+    float coh = p * fast_rcp(p + kEps);
+    float bal = (ml - mr) * fast_rcp(ml + mr + kEps);
+    float h = 0.5f * coh * (1.0f - __builtin_fabsf(bal));
+    c = mk(h * (l.x + r.x), h * (l.y + r.y));
+    ls = l - c;
+    rs = r - c;
+}
+
+// Per-thread state kept in registers across frames.
+struct Thread {
+    cf x[kP];          // FFT working set
+    float acc_l[kP];   // overlap-add state, slot s <-> sample lane + s*LANES of the current frame
+    float acc_r[kP];
+    float acc_c[kP];
+    cf cs[kP / 2];     // centre spectrum of the pair: C_a, then Yc[k]
+    cf part[kP / 2];   // Yc[N-k] of the pair
+};
+
+template <class C>
+struct Stream {
+    static constexpr int N = C::N, LANES = C::LANES, P = kP;
+    using PS = typename C::PS;
+
+    // --- one Stockham pass, split at the LDS exchange ----------------------
+    // inputs of butterfly q are slots q + r*(P/R); pass PI multiplies input r by
+    // W_(NS*R)^(r*k), k = j mod NS, then a radix-R DFT; output r goes to
+    // (j - k) R + k + r NS.
+    template <int PI>
+    static UPX_HD void twiddle_dft(cf (&v)[PS::r[PI]], const Thread& th, const UPX_GLOBAL cf* tw, int lane, int q) {
+        constexpr int R = PS::r[PI];
+        constexpr int NS = pass_ns(PS::r, PI);
+        constexpr int NB = P / R;
+        constexpr int ROW0 = tw_rows_before(PS::r, PI);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = th.x[q + r * NB];
+        if (NS > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r)
+                v[r] = cmul(v[r], opaque(tw + (ROW0 + q * (R - 1) + (r - 1)) * LANES)[lane]);
+        }
+        Dft<R>::run(v);
+    }
+    template <int PI>
+    static UPX_HD void pass_compute_write(Thread& th, cf* lds, const UPX_GLOBAL cf* tw, int lane) {
+        constexpr int R = PS::r[PI];
+        constexpr int NS = pass_ns(PS::r, PI);
+        static_assert(R == P, "passes that write LDS are radix-16 (one butterfly per lane)");
+        static_assert(NS == 1 || NS % 16 == 0, "padding algebra needs NS multiple of 16");
+        cf v[R];
+        twiddle_dft<PI>(v, th, tw, lane, 0);
+        const int k = lane & (NS - 1);
+        // NS == 1: 16 lane + r -> 17 lane + r ; else pad16(base) + r (NS + NS/16)
+        const int pb = NS == 1 ? lane * (R + 1) : pad16((lane - k) * R + k);
+        constexpr int STEP = NS == 1 ? 1 : NS + NS / 16;
+#pragma unroll
+        for (int r = 0; r < R; ++r) lds[pb + r * STEP] = v[r];
+    }
+    // last pass: results stay in registers in natural slot order
+    template <int PI>
+    static UPX_HD void pass_compute_final(Thread& th, const UPX_GLOBAL cf* tw, int lane) {
+        constexpr int R = PS::r[PI];
+        constexpr int NB = P / R;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            cf v[R];
+            twiddle_dft<PI>(v, th, tw, lane, q);
+#pragma unroll
+            for (int r = 0; r < R; ++r) th.x[q + r * NB] = v[r];
+        }
+    }
+    static UPX_HD void read_all(Thread& th, const cf* lds, int lane) {
+        const cf* b = lds + pad16(lane);
+#pragma unroll
+        for (int s = 0; s < P; ++s) th.x[s] = b[s * C::SPITCH];
+    }
+    // upper input slots of an inverse transform: Y[lane + s LANES], s >= P/2, parked at position idx - N/2
+    static UPX_HD void read_upper(Thread& th, const cf* lds, int lane) {
+        const cf* b = lds + pad16(lane);
+#pragma unroll
+        for (int s = P / 2; s < P; ++s) th.x[s] = b[(s - P / 2) * C::SPITCH];
+    }
+
+    // Exchanges of passes 1..n-2 plus the read that precedes the final pass:
+    //   (after W0)  R | W1 | R | ... | W(n-2) | R      ('|' = barrier)
+    template <int PI, class Ex>
+    static UPX_HD void mid(Ex& ex, cf* lds_all, const cf* tw) {
+        ex.each([&](int tid, Thread& th) { read_all(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+        if constexpr (PI < PS::n - 1) {
+            ex.each([&](int tid, Thread& th) {
+                pass_compute_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, opaque(tw), tid % LANES);
+            });
+            mid<PI + 1>(ex, lds_all, tw);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// The band stream program.  `ex.each(f)` = run f on every thread, then barrier.
+// Phases that write LDS are always separated by a barrier from the phase that
+// last read it (single LDS buffer per stream, 2 barriers per exchange).
+// ---------------------------------------------------------------------------
+template <class C, class Ex>
+UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
+    using S = Stream<C>;
+    using PS = typename C::PS;
+    constexpr int N = C::N, LANES = C::LANES, P = kP, HS = C::HS, HOP = C::HOP, K = C::K;
+    constexpr int H = P / 2;        // slots holding own bins k < N/2
+    constexpr int LAST = PS::n - 1; // final pass index
+    constexpr int SP = C::SPITCH;
+
+    const int F = a.blocks_per_stream;
+    const int n_iter = (F + K) / 2;   // frame pairs covering m0-(K-1) .. m0+F-1
+
+    ex.each([&](int, Thread& th) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) th.acc_l[s] = th.acc_r[s] = th.acc_c[s] = 0.f;
+    });
+
+    for (int it = 0; it < n_iter; ++it) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // ---- load + window + forward pass 0 --------------------------
+            ex.each([&](int tid, Thread& th) {
+                const int lane = tid % LANES;
+                const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
+                const int j = m0 - (K - 1) + 2 * it + half;
+                const int j_first = m0 - (K - 1) > a.j_lo ? m0 - (K - 1) : a.j_lo;
+                const int j_end = m0 + F < a.j_hi ? m0 + F : a.j_hi;
+                const bool exists = j >= j_first && j < j_end;
+                const int e = exists ? j * HOP + lane : 0;
+                const UPX_GLOBAL cf* in = opaque(a.in);
+                const UPX_GLOBAL float* w_a = opaque(a.w_a);
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    const bool ok = exists && e + s * LANES < a.t_in;
+                    cf v = opaque(in + s * LANES)[ok ? e : 0];
+                    const float w = ok ? opaque(w_a + s * LANES)[lane] : 0.f;
+                    th.x[s] = mk(v.x * w, v.y * w);
+                }
+                S::template pass_compute_write<0>(th, lds_all + (tid / LANES) * C::PITCH, opaque(a.tw), lane);
+            });
+            S::template mid<1>(ex, lds_all, a.tw);
+            // ---- forward final pass; park the upper half Z[N/2..N) in LDS --
+            ex.each([&](int tid, Thread& th) {
+                const int lane = tid % LANES;
+                cf* b = lds_all + (tid / LANES) * C::PITCH + pad16(lane);
+                S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
+#pragma unroll
+                for (int s = H; s < P; ++s) b[s * SP] = th.x[s];
+            });
+            // ---- split L/R, gain, mask, build iFFT input -----------------
+            // partners Z[N-k] come from the upper region; Y[N-k] goes to the lower
+            // region at position (N-k) - N/2 (position 0 = Nyquist, written by lane 0).
+            ex.each([&](int tid, Thread& th) {
+                cf* lds = lds_all + (tid / LANES) * C::PITCH;
+                const int lane = tid % LANES;
+                const UPX_GLOBAL float* gain = opaque(a.gain);
+                // k_s = lane + s LANES:  pad16(N - k_s) = pad16(N - lane - 7 LANES) + (7 - s) SP  (SP covers LANES, a multiple of 16)
+                const cf* zpart = lds + pad16(N - lane - (H - 1) * LANES);
+                cf* ymir = lds + pad16(N / 2 - lane - (H - 1) * LANES);
+                cf nyq_y = mk(0.f, 0.f);
+                float nyq_c = 0.f;
+                if (lane == 0) {
+                    // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
+                    const float g2 = gain[N / 2];
+                    const cf z = th.x[H];
+                    cf l = mk(g2 * (z.x + z.x), 0.f), r = mk(g2 * (z.y + z.y), 0.f), c, ls, rs;
+                    mask_bin(l, r, c, ls, rs);
+                    nyq_y = mk(ls.x, rs.x);
+                    nyq_c = c.x;
+                }
+#pragma unroll
+                for (int s = 0; s < H; ++s) {
+                    const bool dc = s == 0 && lane == 0;   // k == 0
+                    const float g2 = opaque(gain + s * LANES)[lane];
+                    const cf za = th.x[s];
+                    const cf zp = zpart[(H - 1 - s) * SP];   // for k == 0 this is index N (spare row), unused
+                    const cf zb = dc ? za : zp;              // DC pairs with itself
+                    cf c = mk(0.f, 0.f), ls = c, rs = c;
+                    if (g2 != 0.f) {
+                        cf l = mk(g2 * (za.x + zb.x), g2 * (za.y - zb.y));   // g/2 (Z[k] + conj Z[N-k])
+                        cf r = mk(g2 * (za.y + zb.y), g2 * (zb.x - za.x));   // g/2 (Z[k] - conj Z[N-k]) / i
+                        mask_bin(l, r, c, ls, rs);
+                    }
+                    // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
+                    const cf yk = mk(ls.x - rs.y, ls.y + rs.x);
+                    const cf ym = mk(ls.x + rs.y, rs.x - ls.y);
+                    th.x[s] = cswap(yk);
+                    if (s == 0) {
+                        cf* dst = lane == 0 ? lds : ymir + (H - 1) * SP;   // lane 0: Nyquist at position 0
+                        *dst = cswap(lane == 0 ? nyq_y : ym);
+                    } else {
+                        ymir[(H - 1 - s) * SP] = cswap(ym);
+                    }
+                    // centre spectrum; lane 0 slot 0 packs the two real bins (DC, Nyquist)
+                    const cf cv = dc ? mk(c.x, nyq_c) : c;
+                    if (half == 0) {
+                        th.cs[s] = cv;
+                    } else {
+                        const cf ca = th.cs[s], cb = cv;
+                        // Yc[k] = Ca + i Cb ; Yc[N-k] = conj(Ca) + i conj(Cb)
+                        cf ck = mk(ca.x - cb.y, ca.y + cb.x);
+                        cf cm = mk(ca.x + cb.y, cb.x - ca.y);
+                        if (dc) {
+                            ck = mk(ca.x, cb.x);   // Yc[0]
+                            cm = mk(ca.y, cb.y);   // Yc[N/2]
+                        }
+                        th.cs[s] = cswap(ck);
+                        th.part[s] = cswap(cm);
+                    }
+                }
+            });
+            // ---- upper iFFT input slots come from the lower region -------
+            ex.each([&](int tid, Thread& th) { S::read_upper(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+            // ---- inverse FFT of Ls + i Rs --------------------------------
+            ex.each([&](int tid, Thread& th) {
+                S::template pass_compute_write<0>(th, lds_all + (tid / LANES) * C::PITCH, opaque(a.tw), tid % LANES);
+            });
+            S::template mid<1>(ex, lds_all, a.tw);
+            // ---- final pass, window, overlap-add, emit L/R hop; stage centre pair
+            ex.each([&](int tid, Thread& th) {
+                cf* lds = lds_all + (tid / LANES) * C::PITCH;
+                const int lane = tid % LANES;
+                S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
+                const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
+                const int j = m0 - (K - 1) + 2 * it + half;
+                const UPX_GLOBAL float* w_s = opaque(a.w_s);
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    const float w = opaque(w_s + s * LANES)[lane];
+                    th.acc_l[s] += th.x[s].y * w;   // swapped output: Re y = x.y, Im y = x.x
+                    th.acc_r[s] += th.x[s].x * w;
+                }
+                const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
+                const bool emit = j >= m0 && j < m_end;
+                const int e = emit ? j * HOP + lane : 0;
+                UPX_GLOBAL float* out_l = opaque(a.out_l);
+                UPX_GLOBAL float* out_r = opaque(a.out_r);
+#pragma unroll
+                for (int s = 0; s < HS; ++s) {
+                    if (emit && e + s * LANES < a.t_out) {
+                        UPX_GLOBAL float* pl = opaque(out_l + s * LANES) + e;
+                        UPX_GLOBAL float* pr = opaque(out_r + s * LANES) + e;
+                        if (a.accumulate) {
+                            *pl += th.acc_l[s];
+                            *pr += th.acc_r[s];
+                        } else {
+                            *pl = th.acc_l[s];
+                            *pr = th.acc_r[s];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    th.acc_l[s] = s + HS < P ? th.acc_l[s + HS] : 0.f;
+                    th.acc_r[s] = s + HS < P ? th.acc_r[s + HS] : 0.f;
+                }
+                if (half == 1) {
+                    // centre pair: own bins to registers, mirrored bins to the lower region
+                    cf* ymir = lds + pad16(N / 2 - lane - (H - 1) * LANES);
+#pragma unroll
+                    for (int s = 0; s < H; ++s) {
+                        th.x[s] = th.cs[s];
+                        if (s == 0) {
+                            cf* dst = lane == 0 ? lds : ymir + (H - 1) * SP;
+                            *dst = th.part[0];
+                        } else {
+                            ymir[(H - 1 - s) * SP] = th.part[s];
+                        }
+                    }
+                }
+            });
+        }
+        // ---- centre pair: iFFT of Ca + i Cb ------------------------------
+        ex.each([&](int tid, Thread& th) { S::read_upper(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+        ex.each([&](int tid, Thread& th) {
+            S::template pass_compute_write<0>(th, lds_all + (tid / LANES) * C::PITCH, opaque(a.tw), tid % LANES);
+        });
+        S::template mid<1>(ex, lds_all, a.tw);
+        ex.each([&](int tid, Thread& th) {
+            const int lane = tid % LANES;
+            S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
+            const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
+            const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
+            const UPX_GLOBAL float* w_s = opaque(a.w_s);
+            UPX_GLOBAL float* out_c = opaque(a.out_c);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int j = m0 - (K - 1) + 2 * it + half;
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    const float w = opaque(w_s + s * LANES)[lane];
+                    // swapped output: c_a = Re y = x.y ; c_b = Im y = x.x
+                    th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w;
+                }
+                const bool emit = j >= m0 && j < m_end;
+                const int e = emit ? j * HOP + lane : 0;
+#pragma unroll
+                for (int s = 0; s < HS; ++s) {
+                    if (emit && e + s * LANES < a.t_out) {
+                        UPX_GLOBAL float* pc = opaque(out_c + s * LANES) + e;
+                        if (a.accumulate) *pc += th.acc_c[s];
+                        else *pc = th.acc_c[s];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
+            }
+        });
+    }
+}
+
+// Host-side helper: fill the twiddle table for Cfg (double precision -> float).
+template <class C, class TrigFn>
+inline void fill_twiddles(cf* tw, TrigFn trig) {
+    using PS = typename C::PS;
+    for (int p = 1; p < PS::n; ++p) {
+        const int R = PS::r[p], NS = pass_ns(PS::r, p), NB = kP / R, row0 = tw_rows_before(PS::r, p);
+        for (int q = 0; q < NB; ++q)
+            for (int r = 1; r < R; ++r)
+                for (int lane = 0; lane < C::LANES; ++lane) {
+                    const int k = (lane + q * C::LANES) & (NS - 1);
+                    double c, s;
+                    trig((double)r * (double)k / ((double)NS * (double)R), c, s);   // fraction of a turn
+                    tw[(row0 + q * (R - 1) + (r - 1)) * C::LANES + lane] = mk((float)c, (float)-s);
+                }
+    }
+}
+
+}   // namespace upx

@@ -1,0 +1,594 @@
+// upx_lib.hip - libupmix_hip.so: C ABI (include/upmix_hip.h) + gfx950 kernels.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only; the library is dlopen'ed on first use of upx_comm_*
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <cstdlib>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/upmix_hip.h"
+#include "upx_core.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(UPX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+struct DevExec {
+    upx::Thread st;
+    template <class F>
+    __device__ __forceinline__ void each(F&& f) {
+        f((int)threadIdx.x, st);
+        __syncthreads();
+    }
+};
+
+// WPE = waves per SIMD the register allocator must leave room for (2 -> 256 VGPRs, 3 -> 168).
+template <class C, int WPE>
+__global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec ex;
+    upx::band_program<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+}
+
+__global__ void upx_absmax_kernel(const float* x, long long n, unsigned int* result) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(x[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    // non-negative floats order like their bit patterns
+    if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));
+}
+
+__global__ void upx_scale_kernel(float* x, long long n, float s) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        x[i] *= s;
+}
+
+// seam[row][plane][spill] <- planes[own_len + i]; other rows zero (done by memset)
+__global__ void upx_seam_pack_kernel(float* seam_row, const float* c, const float* l, const float* r,
+                                     long long own_len, long long spill) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < spill; i += (long long)gridDim.x * blockDim.x) {
+        seam_row[i] = c[own_len + i];
+        seam_row[spill + i] = l[own_len + i];
+        seam_row[2 * spill + i] = r[own_len + i];
+    }
+}
+// head of the next shard += spill of the previous one
+__global__ void upx_seam_add_kernel(float* c, float* l, float* r, const float* pc, const float* pl, const float* pr,
+                                    long long spill) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < spill; i += (long long)gridDim.x * blockDim.x) {
+        c[i] += pc[i];
+        l[i] += pl[i];
+        r[i] += pr[i];
+    }
+}
+
+struct KernelEntry {
+    void (*launch)(const upx::BandArgs&, int n_wg, hipStream_t);
+    int (*prepare)();
+    int wg, g, lds_bytes, tw_rows, lanes, wpe;
+    void (*fill_tw)(upx::cf*);
+    const char* name;
+};
+
+void turn_trig(double frac, double& c, double& s) {
+    const double a = 2.0 * M_PI * frac;
+    c = std::cos(a);
+    s = std::sin(a);
+}
+
+template <class C, int WPE>
+struct Entry {
+    static constexpr int kLds = C::G * C::PITCH * (int)sizeof(upx::cf);
+    static void launch(const upx::BandArgs& a, int n_wg, hipStream_t st) {
+        hipLaunchKernelGGL((upx_band_kernel<C, WPE>), dim3(n_wg), dim3(C::WG), kLds, st, a);
+    }
+    static int prepare() {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_band_kernel<C, WPE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    }
+    static void fill(upx::cf* tw) { upx::fill_twiddles<C>(tw, turn_trig); }
+    static KernelEntry get(const char* name) {
+        return KernelEntry{&launch, &prepare, C::WG, C::G, kLds, C::TW_ROWS, C::LANES, WPE, &fill, name};
+    }
+};
+
+// (log2 N, K, variant) -> kernel.  K = N / hop.  Variant 0 is the default build
+// (2 waves/SIMD register budget); variant 1 (hop = N/4 only) trades a few
+// scratch spills for 3 waves/SIMD and is selected with UPX_KERNEL_VARIANT=1.
+const KernelEntry* find_kernel(int log2n, int k, int variant = 0) {
+    static const std::map<std::tuple<int, int, int>, KernelEntry> table = [] {
+        std::map<std::tuple<int, int, int>, KernelEntry> t;
+#define UPX_REG(L, K, W, V) t[std::make_tuple(L, K, V)] = Entry<upx::Cfg<L, K>, W>::get("upx_band_kernel<Cfg<" #L "," #K ">," #W ">");
+        UPX_REG(8, 2, 2, 0) UPX_REG(8, 4, 2, 0) UPX_REG(8, 8, 2, 0)
+        UPX_REG(9, 2, 2, 0) UPX_REG(9, 4, 2, 0) UPX_REG(9, 8, 2, 0)
+        UPX_REG(10, 2, 2, 0) UPX_REG(10, 4, 2, 0) UPX_REG(10, 8, 2, 0)
+        UPX_REG(11, 2, 2, 0) UPX_REG(11, 4, 2, 0) UPX_REG(11, 8, 2, 0)
+        UPX_REG(12, 2, 2, 0) UPX_REG(12, 4, 2, 0) UPX_REG(12, 8, 2, 0)
+        UPX_REG(13, 2, 2, 0) UPX_REG(13, 4, 2, 0) UPX_REG(13, 8, 2, 0)
+        UPX_REG(8, 4, 3, 1) UPX_REG(9, 4, 3, 1) UPX_REG(10, 4, 3, 1) UPX_REG(11, 4, 3, 1) UPX_REG(12, 4, 3, 1)
+        UPX_REG(13, 4, 4, 1)
+#undef UPX_REG
+        return t;
+    }();
+    auto it = table.find(std::make_tuple(log2n, k, variant));
+    if (it == table.end() && variant != 0) it = table.find(std::make_tuple(log2n, k, 0));
+    return it == table.end() ? nullptr : &it->second;
+}
+
+int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+struct BandState {
+    int n = 0, hop = 0, k = 0, log2n = 0;
+    const KernelEntry* kern = nullptr;
+    float* d_wa = nullptr;
+    float* d_ws = nullptr;     // synthesis window / N
+    float* d_gain = nullptr;   // 0.5 * gain
+    upx::cf* d_tw = nullptr;   // shared per N (owned by plan->tw)
+    int blocks_override = 0;
+    int last_wg = 0, last_f = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+}   // namespace
+
+struct upx_plan {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    std::vector<BandState> bands;
+    std::map<int, upx::cf*> tw;   // log2n -> device twiddles
+    bool timing = false;
+    bool timed_once = false;
+    unsigned int* d_scalar = nullptr;
+};
+
+struct upx_comm {
+    upx_plan* plan = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, n_ranks = 1;
+    float* d_seam = nullptr;
+    long long seam_floats = 0;
+};
+
+namespace {
+// ---------------------------------------------------------------------------
+// RCCL through dlopen (so single-GPU use has no RCCL dependency)
+// ---------------------------------------------------------------------------
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+    if (g_rccl.h) return UPX_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(UPX_ERR_RCCL, "cannot dlopen librccl: %s", dlerror());
+    Rccl r;
+    r.h = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString)
+        return fail(UPX_ERR_RCCL, "librccl lacks a required symbol");
+    g_rccl = r;
+    return UPX_OK;
+}
+
+#define NCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        ncclResult_t r_ = (expr);                                                                   \
+        if (r_ != ncclSuccess) return fail(UPX_ERR_RCCL, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+int grid_for(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+}   // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int upx_abi_version(void) { return 1; }
+
+const char* upx_last_error(void) { return g_err.c_str(); }
+
+int upx_device_count(int* count) {
+    if (!count) return fail(UPX_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(UPX_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return UPX_OK;
+}
+
+int upx_supported(int32_t block_size, int32_t hop) {
+    if (block_size < 1 || hop < 1 || block_size % hop) return 0;
+    const int l = ilog2_exact(block_size);
+    if (l < 0) return 0;
+    return find_kernel(l, block_size / hop) ? 1 : 0;
+}
+
+int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* block_size, const int32_t* hop,
+                    const float* w_analysis, const float* w_synthesis, const float* gain) {
+    if (!out || n_bands < 1 || !block_size || !hop || !w_analysis || !w_synthesis || !gain)
+        return fail(UPX_ERR_INVALID, "upx_plan_create: NULL argument or n_bands < 1");
+    for (int b = 0; b < n_bands; ++b) {
+        if (hop[b] < 1) return fail(UPX_ERR_INVALID, "Overlap too large; hop size < 1 is not allowed.");
+        if (!upx_supported(block_size[b], hop[b]))
+            return fail(UPX_ERR_UNSUPPORTED,
+                        "band %d: STFT size %d with hop %d is not covered by the gfx950 kernels "
+                        "(power-of-two sizes 256..8192, hop = N/2, N/4 or N/8)",
+                        b, block_size[b], hop[b]);
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(UPX_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n_dev) return fail(UPX_ERR_INVALID, "device %d out of range (0..%d)", device, n_dev - 1);
+    HIP_TRY(hipSetDevice(device));
+    upx_plan* p = new upx_plan();
+    p->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        p->n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&p->d_scalar, sizeof(unsigned int)));
+    p->bands.resize(n_bands);
+    size_t off_w = 0, off_g = 0;
+    for (int b = 0; b < n_bands; ++b) {
+        BandState& s = p->bands[b];
+        s.n = block_size[b];
+        s.hop = hop[b];
+        s.k = s.n / s.hop;
+        s.log2n = ilog2_exact(s.n);
+        {
+            const char* v = std::getenv("UPX_KERNEL_VARIANT");
+            s.kern = find_kernel(s.log2n, s.k, v ? std::atoi(v) : 0);
+        }
+        if (int e = s.kern->prepare()) {
+            upx_plan_destroy(p);
+            return fail(UPX_ERR_HIP, "hipFuncSetAttribute(%s): %s", s.kern->name, hipGetErrorString((hipError_t)e));
+        }
+        const int nb = s.n / 2 + 1;
+        std::vector<float> ws(s.n), gh(nb);
+        for (int i = 0; i < s.n; ++i) ws[i] = w_synthesis[off_w + i] / (float)s.n;   // exact: N is a power of two
+        for (int i = 0; i < nb; ++i) gh[i] = 0.5f * gain[off_g + i];
+        HIP_TRY(hipMalloc(&s.d_wa, s.n * sizeof(float)));
+        HIP_TRY(hipMalloc(&s.d_ws, s.n * sizeof(float)));
+        HIP_TRY(hipMalloc(&s.d_gain, nb * sizeof(float)));
+        HIP_TRY(hipMemcpy(s.d_wa, w_analysis + off_w, s.n * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s.d_ws, ws.data(), s.n * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s.d_gain, gh.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+        auto it = p->tw.find(s.log2n);
+        if (it == p->tw.end()) {
+            const size_t cnt = (size_t)(s.kern->tw_rows > 0 ? s.kern->tw_rows : 1) * s.kern->lanes;
+            std::vector<upx::cf> host(cnt);
+            s.kern->fill_tw(host.data());
+            upx::cf* d = nullptr;
+            HIP_TRY(hipMalloc(&d, cnt * sizeof(upx::cf)));
+            HIP_TRY(hipMemcpy(d, host.data(), cnt * sizeof(upx::cf), hipMemcpyHostToDevice));
+            it = p->tw.emplace(s.log2n, d).first;
+        }
+        s.d_tw = it->second;
+        HIP_TRY(hipEventCreate(&s.ev0));
+        HIP_TRY(hipEventCreate(&s.ev1));
+        off_w += s.n;
+        off_g += nb;
+    }
+    *out = p;
+    return UPX_OK;
+}
+
+void upx_plan_destroy(upx_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    for (auto& s : p->bands) {
+        if (s.d_wa) (void)hipFree(s.d_wa);
+        if (s.d_ws) (void)hipFree(s.d_ws);
+        if (s.d_gain) (void)hipFree(s.d_gain);
+        if (s.ev0) (void)hipEventDestroy(s.ev0);
+        if (s.ev1) (void)hipEventDestroy(s.ev1);
+    }
+    for (auto& kv : p->tw) (void)hipFree(kv.second);
+    if (p->d_scalar) (void)hipFree(p->d_scalar);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int upx_plan_set_blocks_per_stream(upx_plan* p, int band, int blocks) {
+    if (!p || blocks < 0 || band < -1 || band >= (int)p->bands.size())
+        return fail(UPX_ERR_INVALID, "upx_plan_set_blocks_per_stream: bad argument");
+    for (int b = 0; b < (int)p->bands.size(); ++b)
+        if (band < 0 || band == b) p->bands[b].blocks_override = blocks;
+    return UPX_OK;
+}
+
+int upx_dev_alloc(upx_plan* p, void** ptr, size_t bytes) {
+    if (!p || !ptr) return fail(UPX_ERR_INVALID, "upx_dev_alloc: NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    hipError_t e = hipMalloc(ptr, bytes ? bytes : 4);
+    if (e != hipSuccess) return fail(UPX_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return UPX_OK;
+}
+int upx_dev_free(upx_plan* p, void* ptr) {
+    if (!p) return fail(UPX_ERR_INVALID, "upx_dev_free: NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipFree(ptr));
+    return UPX_OK;
+}
+int upx_dev_memset(upx_plan* p, void* ptr, int value, size_t bytes) {
+    if (!p) return fail(UPX_ERR_INVALID, "upx_dev_memset: NULL plan");
+    HIP_TRY(hipMemsetAsync(ptr, value, bytes, p->stream));
+    return UPX_OK;
+}
+int upx_copy_h2d(upx_plan* p, void* dst, const void* src, size_t bytes) {
+    if (!p) return fail(UPX_ERR_INVALID, "upx_copy_h2d: NULL plan");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return UPX_OK;
+}
+int upx_copy_d2h(upx_plan* p, void* dst, const void* src, size_t bytes) {
+    if (!p) return fail(UPX_ERR_INVALID, "upx_copy_d2h: NULL plan");
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return UPX_OK;
+}
+int upx_sync(upx_plan* p) {
+    if (!p) return fail(UPX_ERR_INVALID, "upx_sync: NULL plan");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return UPX_OK;
+}
+
+int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t own_len, float* d_c, float* d_l,
+                       float* d_r, int64_t t_out) {
+    if (!p || t_in < 0 || own_len < 0 || t_out < 0) return fail(UPX_ERR_INVALID, "upx_process_device: bad argument");
+    if (t_out == 0) return UPX_OK;
+    if (t_in >= (1LL << 29) || t_out >= (1LL << 29))
+        return fail(UPX_ERR_INVALID, "upx_process_device: at most 2^29-1 samples per call (shard longer signals)");
+    if (!d_stereo || !d_c || !d_l || !d_r) return fail(UPX_ERR_INVALID, "upx_process_device: NULL buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    for (size_t b = 0; b < p->bands.size(); ++b) {
+        BandState& s = p->bands[b];
+        const long long j_hi = (own_len + s.hop - 1) / s.hop;       // frames with j*hop < own_len
+        const long long m_all = (t_out + s.hop - 1) / s.hop;        // hop-blocks that intersect [0, t_out)
+        long long m_hi = j_hi + s.k - 1 < m_all ? j_hi + s.k - 1 : m_all;
+        if (b == 0) m_hi = m_all;                                   // first band initialises every output sample
+        if (j_hi > 0x7fffffffLL || m_all > 0x7fffffffLL) return fail(UPX_ERR_INVALID, "signal too long for int32 frame index");
+        if (m_hi <= 0) continue;
+        // blocks per stream: fill every resident workgroup slot once, never fewer than 8 blocks
+        const int resident = (s.kern->wpe * 256) / s.kern->wg > 0 ? (s.kern->wpe * 256) / s.kern->wg : 1;   // workgroups per CU
+        long long target_streams = (long long)p->n_cu * resident * s.kern->g;
+        long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + target_streams - 1) / target_streams;
+        if (s.blocks_override <= 0 && f < 8) f = 8;
+        const long long n_streams = (m_hi + f - 1) / f;
+        const long long n_wg = (n_streams + s.kern->g - 1) / s.kern->g;
+        upx::BandArgs a;
+        a.in = reinterpret_cast<const upx::cf*>(d_stereo);
+        a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
+        a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw = s.d_tw;
+        a.t_in = (int)t_in; a.t_out = (int)t_out;
+        a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
+        a.blocks_per_stream = (int)f;
+        a.accumulate = b == 0 ? 0 : 1;
+        s.last_wg = (int)n_wg;
+        s.last_f = (int)f;
+        if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+        s.kern->launch(a, (int)n_wg, p->stream);
+        if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    p->timed_once = p->timing;
+    return UPX_OK;
+}
+
+int upx_process(upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r) {
+    if (!p || n < 0) return fail(UPX_ERR_INVALID, "upx_process: bad argument");
+    if (n == 0) return UPX_OK;
+    if (!stereo || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process: NULL buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    hipError_t e = hipMalloc(&d_in, (size_t)n * 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * 3 * sizeof(float));
+    if (e != hipSuccess) {
+        if (d_in) (void)hipFree(d_in);
+        return fail(UPX_ERR_NOMEM, "hipMalloc for %lld samples: %s", (long long)n, hipGetErrorString(e));
+    }
+    int rc = UPX_OK;
+    do {
+        if (hipMemcpyAsync(d_in, stereo, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, p->stream) != hipSuccess) {
+            rc = fail(UPX_ERR_HIP, "H2D copy failed");
+            break;
+        }
+        rc = upx_process_device(p, d_in, n, n, d_out, d_out + n, d_out + 2 * n, n);
+        if (rc) break;
+        hipError_t c1 = hipMemcpyAsync(out_c, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+        hipError_t c2 = hipMemcpyAsync(out_l, d_out + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+        hipError_t c3 = hipMemcpyAsync(out_r, d_out + 2 * n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, p->stream);
+        hipError_t c4 = hipStreamSynchronize(p->stream);
+        if (c1 != hipSuccess || c2 != hipSuccess || c3 != hipSuccess || c4 != hipSuccess) {
+            hipError_t bad = c4 != hipSuccess ? c4 : (c1 != hipSuccess ? c1 : (c2 != hipSuccess ? c2 : c3));
+            rc = fail(UPX_ERR_HIP, "kernel or D2H copy failed: %s", hipGetErrorString(bad));
+        }
+    } while (0);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int upx_plan_enable_timing(upx_plan* p, int enable) {
+    if (!p) return fail(UPX_ERR_INVALID, "upx_plan_enable_timing: NULL plan");
+    p->timing = enable != 0;
+    if (!p->timing) p->timed_once = false;
+    return UPX_OK;
+}
+
+int upx_plan_band_times_ms(upx_plan* p, float* ms, int n_bands) {
+    if (!p || !ms || n_bands != (int)p->bands.size()) return fail(UPX_ERR_INVALID, "upx_plan_band_times_ms: bad argument");
+    if (!p->timed_once) return fail(UPX_ERR_INVALID, "no timed upx_process_device call recorded");
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int b = 0; b < n_bands; ++b) {
+        ms[b] = 0.f;
+        if (p->bands[b].last_wg > 0) HIP_TRY(hipEventElapsedTime(&ms[b], p->bands[b].ev0, p->bands[b].ev1));
+    }
+    return UPX_OK;
+}
+
+int upx_plan_band_info(upx_plan* p, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,
+                       int32_t* blocks_per_stream) {
+    if (!p || band < 0 || band >= (int)p->bands.size()) return fail(UPX_ERR_INVALID, "upx_plan_band_info: bad argument");
+    const BandState& s = p->bands[band];
+    if (workgroups) *workgroups = s.last_wg;
+    if (threads) *threads = s.kern->wg;
+    if (lds_bytes) *lds_bytes = s.kern->lds_bytes;
+    if (blocks_per_stream) *blocks_per_stream = s.last_f;
+    return UPX_OK;
+}
+
+int upx_absmax(upx_plan* p, const float* d_x, int64_t n, float* result) {
+    if (!p || !result || n < 0) return fail(UPX_ERR_INVALID, "upx_absmax: bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemsetAsync(p->d_scalar, 0, sizeof(unsigned int), p->stream));
+    if (n > 0) hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_for(n)), dim3(256), 0, p->stream, d_x, (long long)n, p->d_scalar);
+    unsigned int bits = 0;
+    HIP_TRY(hipMemcpyAsync(&bits, p->d_scalar, sizeof bits, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::memcpy(result, &bits, sizeof bits);
+    return UPX_OK;
+}
+
+int upx_scale(upx_plan* p, float* d_x, int64_t n, float scale) {
+    if (!p || n < 0) return fail(UPX_ERR_INVALID, "upx_scale: bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    if (n > 0) hipLaunchKernelGGL(upx_scale_kernel, dim3(grid_for(n)), dim3(256), 0, p->stream, d_x, (long long)n, scale);
+    HIP_TRY(hipGetLastError());
+    return UPX_OK;
+}
+
+// ---- RCCL seam ------------------------------------------------------------
+int upx_comm_unique_id(char* id_out) {
+    if (!id_out) return fail(UPX_ERR_INVALID, "upx_comm_unique_id: NULL");
+    if (int rc = load_rccl()) return rc;
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof id == UPX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    std::memcpy(id_out, &id, sizeof id);
+    return UPX_OK;
+}
+
+int upx_comm_create(upx_comm** out, upx_plan* plan, int rank, int n_ranks, const char* id_bytes) {
+    if (!out || !plan || !id_bytes || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(UPX_ERR_INVALID, "upx_comm_create: bad argument");
+    if (int rc = load_rccl()) return rc;
+    HIP_TRY(hipSetDevice(plan->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof id);
+    upx_comm* c = new upx_comm();
+    c->plan = plan;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(UPX_ERR_RCCL, "ncclCommInitRank(rank %d of %d): %s", rank, n_ranks, g_rccl.GetErrorString(r));
+    }
+    *out = c;
+    return UPX_OK;
+}
+
+void upx_comm_destroy(upx_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->plan->device);
+    if (c->d_seam) (void)hipFree(c->d_seam);
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+int upx_comm_seam_exchange(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill) {
+    if (!c || !d_c || !d_l || !d_r || own_len <= 0 || spill < 0) return fail(UPX_ERR_INVALID, "upx_comm_seam_exchange: bad argument");
+    if (spill == 0 || c->n_ranks == 1) return UPX_OK;
+    upx_plan* p = c->plan;
+    HIP_TRY(hipSetDevice(p->device));
+    const long long row = 3 * (long long)spill, total = row * c->n_ranks;
+    if (c->seam_floats < total) {
+        if (c->d_seam) HIP_TRY(hipFree(c->d_seam));
+        c->d_seam = nullptr;
+        HIP_TRY(hipMalloc(&c->d_seam, (size_t)total * sizeof(float)));
+        c->seam_floats = total;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_seam, 0, (size_t)total * sizeof(float), p->stream));
+    if (c->rank + 1 < c->n_ranks)   // the last rank's spill lies beyond the signal
+        hipLaunchKernelGGL(upx_seam_pack_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream,
+                           c->d_seam + row * c->rank, d_c, d_l, d_r, (long long)own_len, (long long)spill);
+    NCCL_TRY(g_rccl.AllReduce(c->d_seam, c->d_seam, (size_t)total, ncclFloat32, ncclSum, c->comm, p->stream));
+    if (c->rank > 0) {
+        const float* prev = c->d_seam + row * (c->rank - 1);
+        hipLaunchKernelGGL(upx_seam_add_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream, d_c, d_l, d_r, prev,
+                           prev + spill, prev + 2 * spill, (long long)spill);
+    }
+    HIP_TRY(hipGetLastError());
+    return UPX_OK;
+}
+
+int upx_seam_add_local(upx_plan* p, const float* pc, const float* pl, const float* pr, int64_t prev_own_len,
+                       float* nc, float* nl, float* nr, int64_t spill) {
+    if (!p || !pc || !pl || !pr || !nc || !nl || !nr || prev_own_len < 0 || spill < 0)
+        return fail(UPX_ERR_INVALID, "upx_seam_add_local: bad argument");
+    if (spill == 0) return UPX_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    hipLaunchKernelGGL(upx_seam_add_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream, nc, nl, nr,
+                       pc + prev_own_len, pl + prev_own_len, pr + prev_own_len, (long long)spill);
+    HIP_TRY(hipGetLastError());
+    return UPX_OK;
+}
+
+}   // extern "C"
