@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""
+bench.py - headline benchmark: stereo Msamples/s upmixed (6 bands, STFT <= 8192).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (all 6 bands of BASELINE.json configs[2]:
+10 min of 48 kHz stereo, edges 0/30/120/480/1920/7680 Hz, STFT sizes
+[8192,8192,8192,4096,1024,256], Blackman-Harris, 75 % overlap, raised-cosine
+crossovers) over synthetic stereo already resident in HBM.  With N > 1 ranks the
+signal is N x 10 min, time-sharded on the hop_max grid (one 10-min shard per
+GPU, weak scaling) and every step ends with the single RCCL all-reduce of the
+overlap-add seam.  torch.distributed (gloo) is used only
+for the rendezvous, barriers and the max-over-ranks of the wall time; all GPU
+work goes through libupmix_hip.so.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR = 48000
+SECONDS = 600
+EDGES = [0, 30, 120, 480, 1920, 7680]
+MAX_STFT = 8192
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALGO_BYTES_PER_SAMPLE_BAND = 20  # 8 B stereo in + 12 B Ls/C/Rs out, per band
+
+
+def synth(total, seed):
+    rng = np.random.default_rng(seed)
+    m = rng.standard_normal(total)
+    s = rng.standard_normal(total)
+    x = np.empty((total, 2), dtype=np.float32)
+    x[:, 0] = 0.1 * (m + 0.5 * s)
+    x[:, 1] = 0.1 * (m - 0.5 * s)
+    return x
+
+
+def cpu_baseline(sample_seconds=20.0):
+    """The oracle in the reference's scheduling shape (ThreadPoolExecutor, one task per band), bounded sample."""
+    from oracle import upmix_oracle as orc
+    total = int(SR * sample_seconds)
+    x = synth(total, 2).astype(np.float64)
+    bands = orc.plan_bands(EDGES, 0.75, orc.win_blackman_harris, SR, max_block_size=MAX_STFT)
+    t0 = time.perf_counter()
+    orc.extract_multi_band_threadpool(x[:, 0], x[:, 1], bands)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(total / dt / 1e6, 4), "unit": "Msamples/s", "cores": len(bands), "kind": "port",
+        "sample": f"first {sample_seconds:g} s of the same workload (seed 2), oracle/upmix_oracle.py "
+                  f"extract_multi_band_threadpool: ThreadPoolExecutor(), one task per band, float64 numpy.fft, "
+                  f"{os.cpu_count()} host cpus visible, {dt:.1f} s wall",
+    }
+
+
+def load_pmc_traffic(kernel_tag):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary, if present."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+        return rec.get(kernel_tag, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seconds", type=float, default=SECONDS, help="audio per GPU (default: 600 = configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import upmix_amd as ux
+    from upmix_amd import sharding
+
+    own = int(SR * args.seconds)
+    bands = ux.chain_bands(EDGES, 0.75, ux.make_blackman_harris, SR, max_block_size=MAX_STFT, verbose=False,
+                           device=local_rank)
+    plan = ux.DevicePlan(bands, device=local_rank)
+    geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
+    assert own % geo.grid == 0
+    spill = geo.spill if world > 1 else 0
+    halo = geo.halo if (world > 1 and rank + 1 < world) else 0
+
+    # synthetic stereo: shard g = seed (2, g) (N=1: seed 2); right halo = head of the next shard
+    x = synth(own, 2 if world == 1 else (2, rank))
+    if halo:
+        x = np.concatenate([x, synth(own, (2, rank + 1))[:halo]])
+    t_in = x.shape[0]
+    t_out = own + (spill if rank + 1 < world else 0)
+    d_in = plan.alloc(t_in * 8)
+    d_out = [plan.alloc(max(t_out, own + spill) * 4) for _ in range(3)]
+    plan.h2d(d_in, x)
+    del x
+
+    comm = None
+    if world > 1:
+        comm = sharding.RcclSeam(plan, rank, world, broadcast=lambda b: sharding.broadcast_bytes_gloo(dist, b))
+
+    def barrier():
+        plan.sync()
+        if dist is not None:
+            dist.barrier()
+
+    def step():
+        plan.process_device(d_in, t_in, own, d_out[0], d_out[1], d_out[2], t_out)
+        if comm is not None:
+            comm.exchange(d_out, own, spill)
+
+    for _ in range(args.warmup):
+        step()
+    plan.enable_timing(True)
+    band_ms = np.zeros(len(bands))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        band_ms += plan.band_times_ms()   # HIP events on the plan's stream around each band kernel
+    plan.sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    band_ms /= max(args.steps, 1)
+
+    if rank == 0:
+        total_samples = own * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_samples * args.steps / elapsed / 1e6
+        # dominant kernel = the STFT-8192 instantiation (3 launches per step)
+        sizes = [b.block_size for b in bands]
+        by_size = {}
+        for n, ms in zip(sizes, band_ms):
+            by_size.setdefault(n, []).append(ms)
+        dom = max(by_size, key=lambda n: sum(by_size[n]))
+        dom_ms = float(np.mean(by_size[dom]))
+        algo_bytes = ALGO_BYTES_PER_SAMPLE_BAND * own      # one launch = one band over this rank's samples
+        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
+        tag = f"upx_band_kernel<Cfg<{int(np.log2(dom))},4>>"
+        out = {
+            "metric": "stereo Msamples/sec upmixed (6-band, STFT<=8192)",
+            "value": round(value, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[2]: {args.seconds:g} s of 48 kHz stereo per GPU, 6 bands "
+                            f"(edges 0/30/120/480/1920/7680 Hz), STFT {sizes}, Blackman-Harris 75% WOLA, "
+                            f"raised-cosine crossovers XO 0.25, export Ls/C/Rs planes",
+                "samples_per_gpu": own,
+                "x_realtime": round(total_samples / SR / (elapsed / args.steps), 1),
+                "parallelism": "1 GPU" if world == 1 else f"time-sharded x{world}, one RCCL seam all-reduce per step",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": tag,
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": load_pmc_traffic(tag),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_launch_ms": round(dom_ms, 4),
+            },
+            "per_band_ms": [round(float(v), 4) for v in band_ms],
+            "all_bands_algorithmic_GBps": round(ALGO_BYTES_PER_SAMPLE_BAND * len(bands) * own
+                                                / (float(band_ms.sum()) * 1e-3) / 1e9, 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

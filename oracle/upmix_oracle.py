@@ -307,22 +307,27 @@ def band_process_streaming(sig_l: np.ndarray, sig_r: np.ndarray, band: Band):
     return tuple(np.concatenate(p)[:total] for p in pieces)
 
 
-def band_process(sig_l: np.ndarray, sig_r: np.ndarray, band: Band, batch: int = 256):
+def band_process(sig_l: np.ndarray, sig_r: np.ndarray, band: Band, batch: int = 256,
+                 own_len: int = None, out_len: int = None):
     """
     Closed form of the same computation: frames j with
     j*hop < T, input zero-extended on the right, contributions added to the
     float32 output in increasing j.  Returns (c, l, r) float32[T].
+
+    ``own_len`` / ``out_len`` (shard tests only): compute just the frames with
+    j*hop < own_len (they may read input past own_len) and return out_len samples.
     """
     n = band.block_size
     hop = band.hop_size
     total = len(sig_l)
-    n_frames = (total + hop - 1) // hop
+    n_frames = ((total if own_len is None else own_len) + hop - 1) // hop
     g = band_gain(band)
     ext = (n_frames - 1) * hop + n if n_frames > 0 else 0
     xl = np.zeros(ext, dtype=np.float64)
     xr = np.zeros(ext, dtype=np.float64)
-    xl[:total] = sig_l
-    xr[:total] = sig_r
+    m = min(total, ext)
+    xl[:m] = sig_l[:m]
+    xr[:m] = sig_r[:m]
     outs = [np.zeros(ext, dtype=np.float32) for _ in range(3)]
     starts = np.arange(n_frames) * hop
     col = np.arange(n)
@@ -333,7 +338,13 @@ def band_process(sig_l: np.ndarray, sig_r: np.ndarray, band: Band, batch: int = 
             s = int(starts[b0 + j])
             for o, rec in zip(outs, recs):
                 o[s:s + n] += rec[j]
-    return tuple(o[:total].copy() for o in outs)
+    want = total if out_len is None else out_len
+    res = []
+    for o in outs:
+        r = np.zeros(want, dtype=np.float32)
+        r[:min(want, ext)] = o[:min(want, ext)]
+        res.append(r)
+    return tuple(res)
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,134 @@
+"""
+CPU check of the KERNEL SOURCE: upmix_amd/csrc/upx_core.h compiled for the host
+with a sequential workgroup executor (tests/emu/emu.cpp) and compared with the
+oracle.  Catches indexing / LDS layout / framing bugs without a GPU; it is not a
+product path (upmix_amd never loads it).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rms
+from oracle import upmix_oracle as orc
+
+fp = ctypes.POINTER(ctypes.c_float)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import __graft_entry__ as ge
+    path = ge.build_emulator()
+    lib = ctypes.CDLL(path)
+    lib.emu_band.argtypes = [ctypes.c_int, ctypes.c_int, fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong,
+                             fp, fp, fp] + [ctypes.c_int] * 6
+    lib.emu_band.restype = ctypes.c_int
+    return lib
+
+
+def P(a):
+    return a.ctypes.data_as(fp)
+
+
+def run_emu(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=None, t_out=None):
+    n, hop = band.block_size, band.hop_size
+    k = n // hop
+    t_in = len(x)
+    own = t_in if own_len is None else own_len
+    t_out = t_in if t_out is None else t_out
+    j_hi = -(-own // hop)
+    m_hi = min(j_hi + k - 1, -(-t_out // hop)) if accumulate else -(-t_out // hop)
+    w_a = np.ascontiguousarray(band.analysis_window)
+    w_s = (band.synthesis_window / np.float32(n)).astype(np.float32)
+    gain = (0.5 * orc.band_gain(band)).astype(np.float32)
+    if outs is None:
+        outs = [np.full(t_out, np.nan, np.float32) for _ in range(3)]
+    xin = np.ascontiguousarray(x, dtype=np.float32)
+    rc = lib.emu_band(int(np.log2(n)), k, P(xin), t_in, P(outs[0]), P(outs[1]), P(outs[2]), t_out, P(w_a), P(w_s),
+                      P(gain), 0, j_hi, 0, m_hi, blocks_per_stream, accumulate)
+    assert rc == 0
+    return outs
+
+
+CASES = [  # N, T, F, f_low, f_high, width_low, width_high
+    (256, 3000, 5, 7680., 24000., 480., 6000.),
+    (512, 5000, 9, 0., 24000., 0., 6000.),
+    (1024, 9000, 7, 1920., 7680., 480., 1920.),
+    (2048, 12345, 6, 0., 24000., 0., 6000.),
+    (4096, 30000, 4, 480., 1920., 120., 480.),
+    (8192, 40000, 3, 120., 480., 30., 120.),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"N{c[0]}" for c in CASES])
+def test_kernel_source_matches_oracle(emu, case):
+    n, total, f, lo, hi, wl, wh = case
+    band = orc.Band(n, 0.75, lo, hi, 48000, "raised_cosine", wl, wh)
+    x = orc.synthetic_stereo(total, n)
+    ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+    got = run_emu(emu, band, x, f)
+    for g, r in zip(got, ref):
+        assert not np.isnan(g).any()
+        assert rms(g.astype(np.float64) - r) < 1e-7
+
+
+def test_other_overlaps(emu):
+    for n, ov in ((256, 0.5), (1024, 0.5), (1024, 0.875), (4096, 0.875), (8192, 0.5)):
+        band = orc.Band(n, ov, 200., 8000., 44100, "raised_cosine", 50., 2000., window=orc.win_hann)
+        x = orc.synthetic_stereo(4 * n + 123, 3)
+        ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+        got = run_emu(emu, band, x, 5)
+        for g, r in zip(got, ref):
+            assert rms(g.astype(np.float64) - r) < 1e-7, (n, ov)
+
+
+def test_stream_partition_is_invisible(emu):
+    """Any EVEN blocks-per-stream gives bit-identical output (halo frames recomputed, same frame pairing)."""
+    band = orc.Band(1024, 0.75, 300., 3000., 48000, "raised_cosine", 75., 750.)
+    x = orc.synthetic_stereo(20000, 5)
+    base = run_emu(emu, band, x, 1000)
+    for f in (2, 4, 6, 18):
+        for a, b in zip(base, run_emu(emu, band, x, f)):
+            assert np.array_equal(a, b), f
+
+
+def test_band_accumulation_order(emu):
+    """accumulate=1 adds onto the planes written by the previous band (band sum in list order)."""
+    bands = orc.plan_bands([0, 300, 3000], 0.75, orc.win_blackman_harris, 48000, max_block_size=1024)
+    x = orc.synthetic_stereo(9000, 6)
+    outs = None
+    for i, b in enumerate(bands):
+        outs = run_emu(emu, b, x, 6, outs=outs, accumulate=1 if i else 0)
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), bands)
+    for g, r in zip(outs, ref):
+        assert rms(g.astype(np.float64) - r) < 1e-7
+
+
+def test_short_and_ragged_inputs(emu):
+    band = orc.Band(2048, 0.75, 0., 24000., 48000, "raised_cosine", 0., 6000.)
+    for total in (1, 511, 512, 513, 1000, 2048, 2049):
+        x = orc.synthetic_stereo(total, total)
+        ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+        got = run_emu(emu, band, x, 3)
+        for g, r in zip(got, ref):
+            assert g.shape == (total,) and rms(g.astype(np.float64) - r) < 1e-7
+
+
+def test_shard_arguments(emu):
+    """own_len / t_out: only frames starting in the owned range, output spills N-hop past it."""
+    band = orc.Band(1024, 0.75, 300., 3000., 48000, "raised_cosine", 75., 750.)
+    x = orc.synthetic_stereo(8192 + 768, 7)
+    own, t_out = 8192, 8192 + 768
+    ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band, own_len=own, out_len=t_out)
+    got = run_emu(emu, band, x, 4, own_len=own, t_out=t_out)
+    for g, r in zip(got, ref):
+        assert rms(g.astype(np.float64) - r) < 1e-7
+    assert rms(ref[0][own:]) > 0   # the spill is not empty
+
+
+def test_silence_is_exact_zero(emu):
+    band = orc.Band(256, 0.75, 7680., 24000., 48000, "raised_cosine", 480., 6000.)
+    got = run_emu(emu, band, np.zeros((3000, 2), np.float32), 5)
+    assert all(not g.any() for g in got)

@@ -1,0 +1,153 @@
+"""CPU tests of the host side of upmix_amd: planner, windows, gains, export arithmetic, WAV codec, C ABI symbols."""
+import contextlib
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_golden
+from oracle import upmix_oracle as orc
+import upmix_amd as ux
+from upmix_amd import _lib, export, wav
+
+
+def test_plan_tables_match_reference_fixture():
+    rec = json.load(open(os.path.join(GOLDEN, "f0_plan.json")))
+    for f_low, sr, mx, tf, want in rec["block_size"]:
+        assert ux.compute_block_size_for_low_freq(f_low, sr, mx, tf) == want
+    for f, sr, n, want in rec["freq_to_bin"]:
+        assert ux.freq_to_bin(f, sr, n) == want
+    for x, want in rec["next_pow2"]:
+        assert ux.next_power_of_2(x) == want
+    assert ux.hp_freq_to_crossover_width(480.0) == 120.0
+
+
+def test_chain_bands_matches_reference_including_log():
+    rec = json.load(open(os.path.join(GOLDEN, "f0_plan.json")))
+    for ch in rec["chain"]:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            bands = ux.chain_bands(ch["edges"], 0.75, ux.make_rect, ch["sr"])
+        got = [[b.block_size, b.hop_size, b.f_low, b.f_high, b.xover_width_low_hz, b.xover_width_high_hz,
+                b.xover_mode] for b in bands]
+        assert got == ch["bands"]
+        assert buf.getvalue() == ch["log"]          # same per-band print lines
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_rect, 48000, max_block_size=8192, verbose=False)
+    assert [b.block_size for b in bands] == [8192, 8192, 8192, 4096, 1024, 256]
+    bands = ux.chain_bands([0, 300, 3000], 0.75, ux.make_rect, 48000, max_block_size=4096, threshold_factor=64,
+                           verbose=False)
+    assert [b.block_size for b in bands] == [4096, 4096, 1024]
+
+
+def test_windows_and_wola_bit_exact():
+    z = load_golden("f1_windows.npz")
+    for key in z.files:
+        parts = key.split("_")
+        if parts[-1] == "wa":
+            n = int(parts[-2]); name = "_".join(parts[:-2])
+            got = ux.WINDOW_FUNCS[name](n)
+        else:
+            ov = float(parts[-1]); n = int(parts[-3]); name = "_".join(parts[:-3])
+            got = ux.design_wola_synthesis_window(ux.WINDOW_FUNCS[name](n), ov)
+        assert np.array_equal(got, z[key]), key
+
+
+def test_gain_vectors_bit_exact():
+    z = load_golden("f2_gains.npz")
+    plans = {
+        "c3_6band_8192_48k": ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_rect, 48000,
+                                            max_block_size=8192, verbose=False),
+        "c4_6band_8192_96k": ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_rect, 96000,
+                                            max_block_size=8192, verbose=False),
+        "c2_3band_4096_48k": ux.chain_bands([0, 300, 3000], 0.75, ux.make_rect, 48000, max_block_size=4096,
+                                            threshold_factor=64, verbose=False),
+        "hard_300_3000_1024": [ux.MultiBandExtractorAccu(1024, 0.75, ux.make_rect, 300.0, 3000.0, 48000, "hard_zero",
+                                                         75.0, 750.0)],
+        "unknown_mode_1024": [ux.MultiBandExtractorAccu(1024, 0.75, ux.make_rect, 300.0, 3000.0, 48000,
+                                                        "no_such_mode", 75.0, 750.0)],
+    }
+    for name, bands in plans.items():
+        for i, b in enumerate(bands):
+            assert np.array_equal(b.gain_vector(), z[f"{name}_b{i}_N{b.block_size}"]), (name, i)
+
+
+def test_error_behaviour_of_reference():
+    with pytest.raises(ValueError):
+        ux.design_wola_synthesis_window(ux.make_hann(4), 0.9)
+    with pytest.raises(ValueError):
+        ux.MultiBandExtractorAccu(4, 0.9, ux.make_hann, 0.0, 100.0, 48000)
+    b = ux.MultiBandExtractorAccu(256, 0.75, ux.make_hann, 0.0, 100.0, 48000)
+    assert b.xover_mode == "hard_zero" and b.hop_size == 64 and b.accumC.dtype == np.float32
+
+
+def test_export_arithmetic_matches_main_py():
+    z = load_golden("f7_main.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "f7_main.json")))
+    x = z["x"].astype(np.float64)
+    ob = orc.plan_bands([0, 30, 120, 480, 1920, 7680], 0.75, orc.win_blackman_harris, 48000)
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 48000, verbose=False)
+    c0, l0, r0 = orc.extract_multi_band(x[:, 0], x[:, 1], ob)     # stands in for the GPU planes
+    for mode in ("AB", "split", "stereo_sum", "bogus"):
+        c, l, r = c0.copy(), l0.copy(), r0.copy()
+        scale, overall = export.scale_to_input_peak(c, l, r, export.input_peak(x))
+        assert f"Applying scale_factor = {scale:.4f}" in meta[mode]["log_tail"]
+        arrays = export.export_arrays(mode, c, l, r, x[:, 0], x[:, 1])
+        names = export.export_file_names("eyes", mode, bands, 0.75)
+        assert sorted(os.path.join("out", v) for v in names.values()) == meta[mode]["files"]
+        for k, arr in arrays.items():
+            want = z[f"{mode}:{os.path.join('out', names[k])}"]
+            assert arr.dtype == want.dtype and np.array_equal(arr, want), (mode, k)
+    assert export.input_peak(np.zeros((4, 2))) == 1e-9
+
+
+def test_wav_codec_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-0.9, 0.9, size=(1000, 2))
+    # integer PCM is written with full scale 2^(b-1)-1 and read with 2^(b-1) (libsndfile convention): < 2 LSB
+    for subtype, tol in (("PCM_16", 2.0 / 32768), ("PCM_24", 2.0 / 8388608), ("PCM_32", 2.0 / 2 ** 31), ("FLOAT", 1e-7)):
+        p = str(tmp_path / f"t_{subtype}.wav")
+        wav.write(p, x, 44100, subtype)
+        y, sr = wav.read(p)
+        assert sr == 44100 and y.shape == x.shape and y.dtype == np.float64
+        assert np.max(np.abs(y - x)) <= tol
+    p = str(tmp_path / "mono.wav")
+    wav.write(p, x[:, 0], 48000)
+    y, sr = wav.read(p)
+    assert y.ndim == 1 and sr == 48000
+    (tmp_path / "bad.wav").write_bytes(b"nope")
+    with pytest.raises(ValueError):
+        wav.read(str(tmp_path / "bad.wav"))
+
+
+def test_cli_missing_file_raises_like_reference(tmp_path):
+    from upmix_amd import cli
+    with pytest.raises(FileNotFoundError):
+        cli.run("missing.wav", in_dir=str(tmp_path), out_dir=str(tmp_path / "out"))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "upmix_hip.h")).read()
+    declared = set(re.findall(r"\b(upx_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                    # dlopen works without a GPU; raises if the .so is missing
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.upx_abi_version() == 1
+    assert lib.upx_supported(8192, 2048) == 1 and lib.upx_supported(65536, 16384) == 0
+    assert lib.upx_supported(512, 204) == 0
+
+
+def test_no_cpu_fallback_in_product(monkeypatch):
+    """The product path must fail loudly when the HIP library is missing, and never imports the checker."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libupmix_hip.so")
+    with pytest.raises(_lib.UpmixHipError):
+        _lib.load()
+    pkg = os.path.join(ROOT, "upmix_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f

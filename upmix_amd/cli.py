@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""
+WAV in -> Ls/C/Rs WAV out on an MI355X: the flow of python-prototype/main.py
+(load :43, mono->stereo :47-48, peak :53-55, chain_bands :67-73, extract :78-80,
+scale :85-97, export :110-160) with the constants the reference asks the user to
+edit exposed as arguments.  Defaults reproduce main.py (eyes.wav, stereo_sum,
+edges 0/30/120/480/1920/7680, overlap 0.75, Blackman-Harris, raised cosine)
+except --max-stft, which defaults to the largest size the kernels cover.
+
+    python -m upmix_amd.cli eyes.wav --export-mode split
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import export, wav
+from .extractor import chain_bands, extract_center_left_right_multi_band_in_memory
+from .plan import WINDOW_FUNCS
+
+_WRITE_NOTES = {
+    "AB": "[AB] Wrote 2-ch => {path}\n  Left  = (Ls + C + Rs)\n  Right = (L + R)\n",
+    "Ls": "[Split] Wrote => {path} (Left=Ls, Right=0)",
+    "C": "[Split] Wrote => {path} (Left=C, Right=C)",
+    "Rs": "[Split] Wrote => {path} (Left=0, Right=Rs)",
+    "Sum": "[StereoSum] Wrote 2-ch => {path}\n  Left  = (Ls + C/2)\n  Right = (Rs + C/2)\n",
+}
+
+
+def run(in_filename: str = "eyes.wav", export_mode: str = "stereo_sum", in_dir: str = "in", out_dir: str = "out",
+        band_edges=(0, 30, 120, 480, 1920, 7680), overlap: float = 0.75, window: str = "blackman_harris",
+        xover_mode: str = "raised_cosine", max_stft: int = 8192, threshold_factor: float = 32,
+        xo_fraction: float = 0.25, device: int = 0, subtype: str = "PCM_16", reader=wav.read, writer=wav.write):
+    """One file through the path; returns {name: path} of the files written."""
+    os.makedirs(out_dir, exist_ok=True)
+    in_path = os.path.join(in_dir, in_filename)
+    if not os.path.isfile(in_path):
+        raise FileNotFoundError(f"File not found: {in_path}")
+    wave, sr = reader(in_path)
+    print(f"Loaded '{in_path}', sr={sr}, shape={wave.shape}")
+    if wave.ndim == 1:
+        wave = np.column_stack([wave, wave])
+    L = wave[:, 0]
+    R = wave[:, 1]
+    peak_in = export.input_peak(wave)
+
+    band_extractors = chain_bands(list(band_edges), overlap, WINDOW_FUNCS[window], sr, xover_mode,
+                                  max_block_size=max_stft, threshold_factor=threshold_factor,
+                                  xo_fraction=xo_fraction, device=device)
+    final_center, final_left, final_right = extract_center_left_right_multi_band_in_memory(
+        L, R, sr, band_extractors, device=device)
+
+    scale_factor, overall_peak = export.scale_to_input_peak(final_center, final_left, final_right, peak_in)
+    print(f"Original peak = {peak_in:.4f}, L/C/R peak = {overall_peak:.4f}")
+    print(f"Applying scale_factor = {scale_factor:.4f}")
+
+    base_in_name = os.path.splitext(in_filename)[0]
+    arrays = export.export_arrays(export_mode, final_center, final_left, final_right, L, R)
+    names = export.export_file_names(base_in_name, export_mode, band_extractors, overlap)
+    written = {}
+    if not arrays:
+        print(f"Unknown export_mode '{export_mode}' -- no files written.")
+    for key in ("AB", "Ls", "C", "Rs", "Sum"):
+        if key in arrays:
+            path = os.path.join(out_dir, names[key])
+            if writer is wav.write:
+                writer(path, arrays[key], sr, subtype)
+            else:
+                writer(path, arrays[key], sr)
+            print(_WRITE_NOTES[key].format(path=path))
+            written[key] = path
+    print("Done.")
+    return written
+
+
+def main(argv=None) -> int:
+    ap = argparse.ArgumentParser(prog="upmix_amd.cli", description=__doc__.split("\n\n")[0])
+    ap.add_argument("in_filename", nargs="?", default="eyes.wav", help="WAV name inside --in-dir")
+    ap.add_argument("--export-mode", default="stereo_sum", help="AB | split | stereo_sum")
+    ap.add_argument("--in-dir", default="in")
+    ap.add_argument("--out-dir", default="out")
+    ap.add_argument("--band-edges", default="0,30,120,480,1920,7680", help="comma-separated Hz")
+    ap.add_argument("--overlap", type=float, default=0.75)
+    ap.add_argument("--window", default="blackman_harris", choices=sorted(WINDOW_FUNCS))
+    ap.add_argument("--xover-mode", default="raised_cosine")
+    ap.add_argument("--max-stft", type=int, default=8192, help="max STFT size (reference: 65536)")
+    ap.add_argument("--threshold-factor", type=float, default=32)
+    ap.add_argument("--xo-fraction", type=float, default=0.25)
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--subtype", default="PCM_16", choices=["PCM_16", "PCM_24", "PCM_32", "FLOAT"])
+    a = ap.parse_args(argv)
+    run(a.in_filename, a.export_mode, a.in_dir, a.out_dir, [float(v) for v in a.band_edges.split(",")], a.overlap,
+        a.window, a.xover_mode, a.max_stft, a.threshold_factor, a.xo_fraction, a.device, a.subtype)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

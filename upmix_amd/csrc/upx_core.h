@@ -363,8 +363,12 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     constexpr int LAST = PS::n - 1; // final pass index
     constexpr int SP = C::SPITCH;
 
+    // Frames are transformed in pairs (a, b) = (odd j, j+1) so that one inverse FFT
+    // returns the centre signal of both.  With F even and m_lo even every stream
+    // starts on an 'a' frame (m0-(K-1) is odd), so the pairing - and therefore every
+    // rounding - is independent of blocks_per_stream, CU count and sharding.
     const int F = a.blocks_per_stream;
-    const int n_iter = (F + K) / 2;   // frame pairs covering m0-(K-1) .. m0+F-1
+    const int n_iter = (F + K + 1) / 2;   // frame pairs covering m0-(K-1) .. m0+F
 
     ex.each([&](int, Thread& th) {
 #pragma unroll
@@ -380,16 +384,21 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
                 const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
                 const int j = m0 - (K - 1) + 2 * it + half;
                 const int j_first = m0 - (K - 1) > a.j_lo ? m0 - (K - 1) : a.j_lo;
-                const int j_end = m0 + F < a.j_hi ? m0 + F : a.j_hi;
+                // one frame past the emitted range is still transformed: it is the pair partner of
+                // frame m0+F-1 (for even F), and pairing must not depend on how streams are cut
+                const int j_end = m0 + F + 1 < a.j_hi ? m0 + F + 1 : a.j_hi;
                 const bool exists = j >= j_first && j < j_end;
                 const int e = exists ? j * HOP + lane : 0;
                 const UPX_GLOBAL cf* in = opaque(a.in);
                 const UPX_GLOBAL float* w_a = opaque(a.w_a);
+                const int last = a.t_in - 1;   // host guarantees t_in >= 1
 #pragma unroll
                 for (int s = 0; s < P; ++s) {
-                    const bool ok = exists && e + s * LANES < a.t_in;
-                    cf v = opaque(in + s * LANES)[ok ? e : 0];
-                    const float w = ok ? opaque(w_a + s * LANES)[lane] : 0.f;
+                    // always load an in-range sample, then zero what lies past the signal or in a
+                    // frame this stream does not own (zero-extension of center_extraction.py:437-455)
+                    const int n = e + s * LANES;
+                    const cf v = in[n < last ? n : last];
+                    const float w = (exists && n <= last) ? opaque(w_a + s * LANES)[lane] : 0.f;
                     th.x[s] = mk(v.x * w, v.y * w);
                 }
                 S::template pass_compute_write<0>(th, lds_all + (tid / LANES) * C::PITCH, opaque(a.tw), lane);

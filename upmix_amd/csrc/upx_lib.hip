@@ -397,6 +397,13 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         return fail(UPX_ERR_INVALID, "upx_process_device: at most 2^29-1 samples per call (shard longer signals)");
     if (!d_stereo || !d_c || !d_l || !d_r) return fail(UPX_ERR_INVALID, "upx_process_device: NULL buffer");
     HIP_TRY(hipSetDevice(p->device));
+    if (t_in == 0 || own_len == 0) {   // nothing to transform: the result is silence
+        HIP_TRY(hipMemsetAsync(d_c, 0, (size_t)t_out * sizeof(float), p->stream));
+        HIP_TRY(hipMemsetAsync(d_l, 0, (size_t)t_out * sizeof(float), p->stream));
+        HIP_TRY(hipMemsetAsync(d_r, 0, (size_t)t_out * sizeof(float), p->stream));
+        for (auto& s : p->bands) s.last_wg = 0;
+        return UPX_OK;
+    }
     for (size_t b = 0; b < p->bands.size(); ++b) {
         BandState& s = p->bands[b];
         const long long j_hi = (own_len + s.hop - 1) / s.hop;       // frames with j*hop < own_len
@@ -410,6 +417,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         long long target_streams = (long long)p->n_cu * resident * s.kern->g;
         long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + target_streams - 1) / target_streams;
         if (s.blocks_override <= 0 && f < 8) f = 8;
+        f += f & 1;   // even: keeps the (odd, even) frame pairing identical for every partition
         const long long n_streams = (m_hi + f - 1) / f;
         const long long n_wg = (n_streams + s.kern->g - 1) / s.kern->g;
         upx::BandArgs a;

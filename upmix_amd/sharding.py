@@ -1,0 +1,175 @@
+"""
+Time sharding of the hot path.
+
+Frames are independent given their input window; the only coupling is the
+linear overlap-add.  A signal is cut on a grid of hop_max = max_b hop_b (every
+smaller hop divides it), shard g owns samples [s_g, s_g+1) and every frame of
+every band that STARTS there, so the band sum stays local.  It reads a right
+halo of max_b (N_b - hop_b) input samples and its output spills the same number
+of samples past s_g+1; that spill is the seam: one all-reduce over
+seam[G][3][spill] (RCCL across GPUs), after which shard g+1 adds row g to its
+head.  The reference has no counterpart (single process, center_extraction.py:477-513).
+
+The arithmetic here is engine-agnostic: `engine(local_stereo, own_len, t_out)`
+returns the three planes of one shard.  The product engine is the HIP library
+(DevicePlan); the CPU tests plug the oracle in to check the seam algebra with
+world_size-2 gloo.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclass
+class Shard:
+    index: int
+    start: int        # first owned sample (global)
+    own_len: int      # owned samples
+    t_in: int         # input samples to hand to the engine, from `start`
+    t_out: int        # output plane length: own_len (+ spill unless last)
+    last: bool
+
+
+class ShardGeometry:
+    def __init__(self, block_sizes: Sequence[int], hops: Sequence[int]):
+        self.block_sizes = [int(n) for n in block_sizes]
+        self.hops = [int(h) for h in hops]
+        self.hop_max = max(self.hops)
+        for h in self.hops:
+            if self.hop_max % h:
+                raise ValueError(f"hop {h} does not divide hop_max {self.hop_max}: bands cannot share a shard grid")
+        # shard boundaries sit on multiples of 2*hop_max so that local frame parity == global frame
+        # parity in every band (the kernels transform frames in (odd, even) pairs)
+        self.grid = 2 * self.hop_max
+        self.spill = max(n - h for n, h in zip(self.block_sizes, self.hops))
+        self.halo = self.spill
+
+    def plan(self, total: int, n_shards: int) -> List[Shard]:
+        """Cut [0, total) into n_shards contiguous ranges on the 2*hop_max grid (last one takes the remainder)."""
+        if n_shards < 1:
+            raise ValueError("n_shards must be >= 1")
+        cells = -(-total // self.grid)
+        if n_shards > 1 and cells // n_shards * self.grid < self.spill:
+            raise ValueError(f"signal of {total} samples is too short for {n_shards} shards "
+                             f"(each must own at least {self.spill} samples)")
+        base, extra = divmod(cells, n_shards)
+        shards, start = [], 0
+        for g in range(n_shards):
+            n_cells = base + (1 if g < extra else 0)
+            last = g == n_shards - 1
+            end = total if last else start + n_cells * self.grid
+            own = end - start
+            shards.append(Shard(g, start, own, min(total - start, own + (0 if last else self.halo)),
+                                own + (0 if last else self.spill), last))
+            start = end
+        return shards
+
+
+def pack_seam(planes: Sequence[np.ndarray], shard: Shard, n_shards: int, spill: int) -> np.ndarray:
+    """seam[G][3][spill] with this shard's spill in its own row (zero elsewhere; the last shard has none)."""
+    seam = np.zeros((n_shards, 3, spill), dtype=np.float32)
+    if not shard.last:
+        for p, plane in enumerate(planes):
+            seam[shard.index, p, :] = plane[shard.own_len:shard.own_len + spill]
+    return seam
+
+
+def apply_seam(planes: Sequence[np.ndarray], shard: Shard, seam: np.ndarray) -> None:
+    """Add the previous shard's spill onto this shard's head (in place)."""
+    if shard.index == 0:
+        return
+    spill = seam.shape[2]
+    n = min(spill, len(planes[0]))
+    for p, plane in enumerate(planes):
+        plane[:n] += seam[shard.index - 1, p, :n]
+
+
+def run_shard(stereo: np.ndarray, geo: ShardGeometry, shard: Shard, n_shards: int,
+              engine: Callable[[np.ndarray, int, int], Tuple[np.ndarray, np.ndarray, np.ndarray]],
+              allreduce: Callable[[np.ndarray], np.ndarray]) -> Tuple[np.ndarray, ...]:
+    """One rank's work: engine on the local window, seam all-reduce, head fix-up, trim to the owned range."""
+    local = stereo[shard.start:shard.start + shard.t_in]
+    planes = [np.array(p, dtype=np.float32, copy=True) for p in engine(local, shard.own_len, shard.t_out)]
+    if n_shards > 1:
+        seam = allreduce(pack_seam(planes, shard, n_shards, geo.spill))
+        apply_seam(planes, shard, seam)
+    return tuple(p[:shard.own_len] for p in planes)
+
+
+# ---------------------------------------------------------------------------
+# product engines
+# ---------------------------------------------------------------------------
+def process_sharded_single_device(plan, stereo: np.ndarray, max_shard: int = 1 << 27):
+    """
+    Whole signal on ONE device in several launches (signals longer than a launch can
+    index, or larger than HBM): shards run one after another, the seam is added on
+    the device with upx_seam_add_local.
+    """
+    total = stereo.shape[0]
+    geo = ShardGeometry(plan.block_sizes, plan.hops)
+    n_shards = max(1, -(-total // max_shard))
+    shards = geo.plan(total, n_shards)
+    outs = [np.empty(total, dtype=np.float32) for _ in range(3)]
+    cap_in = max(s.t_in for s in shards)
+    cap_out = max(s.t_out for s in shards)
+    d_in = plan.alloc(cap_in * 8)
+    bufs = [[plan.alloc(cap_out * 4) for _ in range(3)] for _ in range(2)]
+    try:
+        prev: Optional[Shard] = None
+        for s in shards:
+            cur, old = bufs[s.index % 2], bufs[(s.index + 1) % 2]
+            plan.h2d(d_in, stereo[s.start:s.start + s.t_in])
+            plan.process_device(d_in, s.t_in, s.own_len, cur[0], cur[1], cur[2], s.t_out)
+            if prev is not None:
+                plan.seam_add_local(old, prev.own_len, cur, min(geo.spill, s.t_out))
+            for o, d in zip(outs, cur):
+                plan.d2h(o[s.start:s.start + s.own_len], d)
+            prev = s
+    finally:
+        plan.free(d_in)
+        for pair in bufs:
+            for b in pair:
+                plan.free(b)
+    return tuple(outs)
+
+
+class RcclSeam:
+    """One RCCL communicator per process/GPU for the seam all-reduce (upx_comm_* in the C ABI)."""
+
+    def __init__(self, plan, rank: int, world: int, broadcast: Callable[[Optional[bytes]], bytes]):
+        self._lib = _lib.load()
+        self.plan = plan
+        uid = None
+        if rank == 0:
+            buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+            _lib.check(self._lib.upx_comm_unique_id(buf))
+            uid = buf.raw
+        uid = broadcast(uid)
+        handle = C.c_void_p()
+        _lib.check(self._lib.upx_comm_create(C.byref(handle), plan.handle, rank, world, uid))
+        self.handle = handle
+
+    def exchange(self, d_planes: Sequence[int], own_len: int, spill: int) -> None:
+        _lib.check(self._lib.upx_comm_seam_exchange(self.handle, *(C.c_void_p(p) for p in d_planes),
+                                                    int(own_len), int(spill)))
+
+    def close(self) -> None:
+        if self.handle:
+            self._lib.upx_comm_destroy(self.handle)
+            self.handle = None
+
+
+def broadcast_bytes_gloo(dist, payload: Optional[bytes], nbytes: int = _lib.UNIQUE_ID_BYTES) -> bytes:
+    """Share rank 0's bytes with every rank over an existing torch.distributed (gloo) group."""
+    import torch
+    t = torch.zeros(nbytes, dtype=torch.uint8)
+    if payload is not None:
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    dist.broadcast(t, src=0)
+    return bytes(t.numpy().tobytes())

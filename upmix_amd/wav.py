@@ -1,0 +1,94 @@
+"""
+Minimal WAV codec (stdlib + NumPy) so the WAV-in / WAV-out surface of main.py
+(main.py:43, :119, :132-140, :153) does not depend on python-soundfile, which is
+absent from the image.  Reads PCM 8/16/24/32-bit and IEEE float 32/64 (plain
+and WAVE_FORMAT_EXTENSIBLE); ``read`` returns float64 in [-1, 1) like
+``soundfile.read``.  ``write`` defaults to PCM_16 like ``soundfile.write`` does
+for .wav.  Byte-level parity with libsndfile is not claimed.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Tuple
+
+import numpy as np
+
+_PCM, _FLOAT, _EXT = 1, 3, 0xFFFE
+
+
+def read(path: str) -> Tuple[np.ndarray, int]:
+    """-> (data float64 [T] or [T, channels], sample_rate)."""
+    with open(path, "rb") as fh:
+        blob = fh.read()
+    if len(blob) < 12 or blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(blob):
+        tag, size = blob[pos:pos + 4], struct.unpack("<I", blob[pos + 4:pos + 8])[0]
+        body = blob[pos + 8:pos + 8 + size]
+        if tag == b"fmt ":
+            fmt = body
+        elif tag == b"data":
+            data = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError(f"{path}: missing fmt or data chunk")
+    code, channels, rate, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if code == _EXT and len(fmt) >= 26:
+        code = struct.unpack("<H", fmt[24:26])[0]
+    width = bits // 8
+    count = len(data) // (width * channels) * channels
+    raw = data[:count * width]
+    if code == _FLOAT and bits == 32:
+        x = np.frombuffer(raw, dtype="<f4").astype(np.float64)
+    elif code == _FLOAT and bits == 64:
+        x = np.frombuffer(raw, dtype="<f8").astype(np.float64)
+    elif code == _PCM and bits == 8:
+        x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float64) - 128.0) / 128.0
+    elif code == _PCM and bits == 16:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
+    elif code == _PCM and bits == 24:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - 0x1000000, v)
+        x = v.astype(np.float64) / 8388608.0
+    elif code == _PCM and bits == 32:
+        x = np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0
+    else:
+        raise ValueError(f"{path}: unsupported WAV encoding (format {code}, {bits} bits)")
+    if channels > 1:
+        x = x.reshape(-1, channels)
+    return x, int(rate)
+
+
+def write(path: str, data: np.ndarray, samplerate: int, subtype: str = "PCM_16") -> None:
+    """data [T] or [T, channels], float in [-1, 1]; subtype PCM_16 | PCM_24 | PCM_32 | FLOAT."""
+    x = np.asarray(data)
+    if x.ndim == 1:
+        x = x[:, None]
+    channels = x.shape[1]
+    x = x.astype(np.float64)
+    if subtype == "FLOAT":
+        code, bits, payload = _FLOAT, 32, x.astype("<f4").tobytes()
+    elif subtype in ("PCM_16", "PCM_24", "PCM_32"):
+        bits = int(subtype[4:])
+        full = float(2 ** (bits - 1) - 1)
+        q = np.clip(np.rint(x * full), -full - 1, full).astype(np.int64)
+        code = _PCM
+        if bits == 16:
+            payload = q.astype("<i2").tobytes()
+        elif bits == 32:
+            payload = q.astype("<i4").tobytes()
+        else:
+            u = (q & 0xFFFFFF).astype(np.uint32).reshape(-1)
+            payload = np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=1).astype(np.uint8).tobytes()
+    else:
+        raise ValueError(f"unsupported subtype {subtype!r}")
+    block = channels * bits // 8
+    fmt = struct.pack("<HHIIHH", code, channels, int(samplerate), int(samplerate) * block, block, bits)
+    with open(path, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(payload) + (len(payload) & 1)) + b"WAVE")
+        fh.write(b"fmt " + struct.pack("<I", len(fmt)) + fmt)
+        fh.write(b"data" + struct.pack("<I", len(payload)) + payload)
+        if len(payload) & 1:
+            fh.write(b"\x00")
