@@ -102,23 +102,23 @@ def main():
     import upmix_amd as ux
     from upmix_amd import sharding
 
-    own = int(SR * args.seconds)
+    nominal = int(SR * args.seconds)
     bands = ux.chain_bands(EDGES, 0.75, ux.make_blackman_harris, SR, max_block_size=MAX_STFT, verbose=False,
                            device=local_rank)
     plan = ux.DevicePlan(bands, device=local_rank)
     geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
-    assert own % geo.grid == 0
+    # N ranks: one signal of N x 10 min cut on the shard grid; rank g owns shard g (+ right halo, + spill)
+    shards = geo.plan(nominal * world, world)
+    shard = shards[rank]
+    own, t_in, t_out = shard.own_len, shard.t_in, shard.t_out
     spill = geo.spill if world > 1 else 0
-    halo = geo.halo if (world > 1 and rank + 1 < world) else 0
 
     # synthetic stereo: shard g = seed (2, g) (N=1: seed 2); right halo = head of the next shard
     x = synth(own, 2 if world == 1 else (2, rank))
-    if halo:
-        x = np.concatenate([x, synth(own, (2, rank + 1))[:halo]])
-    t_in = x.shape[0]
-    t_out = own + (spill if rank + 1 < world else 0)
+    if t_in > own:
+        x = np.concatenate([x, synth(shards[rank + 1].own_len, (2, rank + 1))[:t_in - own]])
     d_in = plan.alloc(t_in * 8)
-    d_out = [plan.alloc(max(t_out, own + spill) * 4) for _ in range(3)]
+    d_out = [plan.alloc((own + spill) * 4) for _ in range(3)]
     plan.h2d(d_in, x)
     del x
 
@@ -157,7 +157,7 @@ def main():
     band_ms /= max(args.steps, 1)
 
     if rank == 0:
-        total_samples = own * world
+        total_samples = nominal * world
         ms_per_step = elapsed / args.steps * 1e3
         value = total_samples * args.steps / elapsed / 1e6
         # dominant kernel = the STFT-8192 instantiation (3 launches per step)
@@ -187,7 +187,7 @@ def main():
                 "workload": f"BASELINE configs[2]: {args.seconds:g} s of 48 kHz stereo per GPU, 6 bands "
                             f"(edges 0/30/120/480/1920/7680 Hz), STFT {sizes}, Blackman-Harris 75% WOLA, "
                             f"raised-cosine crossovers XO 0.25, export Ls/C/Rs planes",
-                "samples_per_gpu": own,
+                "samples_per_gpu": nominal,
                 "x_realtime": round(total_samples / SR / (elapsed / args.steps), 1),
                 "parallelism": "1 GPU" if world == 1 else f"time-sharded x{world}, one RCCL seam all-reduce per step",
             },

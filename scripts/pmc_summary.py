@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc CSVs (gpurun_out/pmc_<tag>/<pass>/**/_counter_collection.csv) per kernel."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"pmc_{tag}")
+acc = defaultdict(lambda: defaultdict(float))
+calls = defaultdict(lambda: defaultdict(set))
+for path in glob.glob(os.path.join(root, "*", "**", "*_counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(path)):
+        name = row["Kernel_Name"]
+        if "upx_band_kernel" not in name:
+            continue
+        key = name[name.index("upx_band_kernel"):name.index("(upx")]
+        acc[key][row["Counter_Name"]] += float(row["Counter_Value"])
+        calls[key][row["Counter_Name"]].add(row["Dispatch_Id"])
+out = {}
+for k in sorted(acc):
+    out[k] = {c: acc[k][c] / max(len(calls[k][c]), 1) for c in sorted(acc[k])}
+    out[k]["_launches_seen"] = max(len(v) for v in calls[k].values())
+print(json.dumps(out, indent=1))

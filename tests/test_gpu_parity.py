@@ -122,7 +122,9 @@ def test_golden_degenerate_inputs(ux):
         if tag == "silence":
             assert not any(o.any() for o in out)          # exact zeros, no NaN
         if tag == "r_zero":
-            assert rms(out[0]) < 1e-9                     # no centre when one channel is empty
+            # the reference gives exactly 0 here; L and R share one complex FFT on the GPU, so R's spectrum
+            # is rounding noise (~1e-8 |L|) instead of 0 and a centre of that order appears
+            assert rms(out[0]) < 1e-7
         if tag == "l_eq_r":
             assert rms(out[1]) < 1e-7 and rms(out[2]) < 1e-7   # mono -> everything in the centre
 
