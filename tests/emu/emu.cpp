@@ -11,8 +11,9 @@
 #include "../../upmix_amd/csrc/upx_core.h"
 
 namespace {
+template <int PTS>
 struct SeqExec {
-    std::vector<upx::Thread> st;
+    std::vector<upx::ThreadT<PTS>> st;
     template <class F>
     void each(F&& f) {
         for (size_t t = 0; t < st.size(); ++t) f((int)t, st[t]);
@@ -34,9 +35,9 @@ int run(upx::BandArgs a) {
     if (n_blocks <= 0) return 0;
     const long long n_streams = (n_blocks + a.blocks_per_stream - 1) / a.blocks_per_stream;
     const long long n_wg = (n_streams + C::G - 1) / C::G;
-    std::vector<upx::cf> lds((size_t)C::G * C::PITCH);
+    std::vector<upx::cf> lds((size_t)C::LDS_CF);
     for (long long wg = 0; wg < n_wg; ++wg) {
-        SeqExec ex;
+        SeqExec<C::P> ex;
         ex.st.resize(C::WG);
         // poison LDS so that reads of never-written cells are visible
         for (auto& v : lds) v = upx::mk(NAN, NAN);
@@ -46,7 +47,7 @@ int run(upx::BandArgs a) {
 }
 }   // namespace
 
-extern "C" int emu_band(int log2n, int k_overlap, const float* in, long long t_in, float* out_c, float* out_l,
+extern "C" int emu_band(int log2n, int k_overlap, int pts, const float* in, long long t_in, float* out_c, float* out_l,
                         float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
                         const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int blocks_per_stream,
                         int accumulate) {
@@ -58,9 +59,11 @@ extern "C" int emu_band(int log2n, int k_overlap, const float* in, long long t_i
     a.t_in = (int)t_in; a.t_out = (int)t_out;
     a.j_lo = j_lo; a.j_hi = j_hi; a.m_lo = m_lo; a.m_hi = m_hi;
     a.blocks_per_stream = blocks_per_stream; a.accumulate = accumulate;
-#define UPX_CASE(L, K) if (log2n == L && k_overlap == K) return run<upx::Cfg<L, K>>(a);
-    UPX_CASE(8, 4) UPX_CASE(9, 4) UPX_CASE(10, 4) UPX_CASE(11, 4) UPX_CASE(12, 4) UPX_CASE(13, 4)
-    UPX_CASE(8, 2) UPX_CASE(10, 2) UPX_CASE(10, 8) UPX_CASE(12, 8) UPX_CASE(13, 2)
+#define UPX_CASE(L, K, PP) if (log2n == L && k_overlap == K && pts == PP) return run<upx::Cfg<L, K, PP>>(a);
+    UPX_CASE(8, 4, 16) UPX_CASE(9, 4, 16) UPX_CASE(10, 4, 16) UPX_CASE(11, 4, 16) UPX_CASE(12, 4, 16) UPX_CASE(13, 4, 16)
+    UPX_CASE(8, 2, 16) UPX_CASE(10, 2, 16) UPX_CASE(10, 8, 16) UPX_CASE(12, 8, 16) UPX_CASE(13, 2, 16)
+    UPX_CASE(8, 4, 8) UPX_CASE(9, 4, 8) UPX_CASE(10, 4, 8) UPX_CASE(11, 4, 8) UPX_CASE(12, 4, 8) UPX_CASE(13, 4, 8)
+    UPX_CASE(8, 2, 8) UPX_CASE(10, 2, 8) UPX_CASE(10, 8, 8) UPX_CASE(12, 8, 8) UPX_CASE(13, 2, 8)
 #undef UPX_CASE
     return -1;
 }

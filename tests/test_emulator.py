@@ -15,6 +15,13 @@ from conftest import ROOT, rms
 from oracle import upmix_oracle as orc
 
 fp = ctypes.POINTER(ctypes.c_float)
+PTS = [16]   # points per lane used by run_emu (switched by the `pts` fixture)
+
+
+@pytest.fixture(autouse=True, params=[16, 8], ids=["P16", "P8"])
+def pts(request):
+    PTS[0] = request.param
+    return request.param
 
 
 @pytest.fixture(scope="module")
@@ -22,7 +29,7 @@ def emu():
     import __graft_entry__ as ge
     path = ge.build_emulator()
     lib = ctypes.CDLL(path)
-    lib.emu_band.argtypes = [ctypes.c_int, ctypes.c_int, fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong,
+    lib.emu_band.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong,
                              fp, fp, fp] + [ctypes.c_int] * 6
     lib.emu_band.restype = ctypes.c_int
     return lib
@@ -32,7 +39,8 @@ def P(a):
     return a.ctypes.data_as(fp)
 
 
-def run_emu(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=None, t_out=None):
+def run_emu(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=None, t_out=None, pts=None):
+    pts = pts or PTS[0]
     n, hop = band.block_size, band.hop_size
     k = n // hop
     t_in = len(x)
@@ -46,7 +54,7 @@ def run_emu(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=No
     if outs is None:
         outs = [np.full(t_out, np.nan, np.float32) for _ in range(3)]
     xin = np.ascontiguousarray(x, dtype=np.float32)
-    rc = lib.emu_band(int(np.log2(n)), k, P(xin), t_in, P(outs[0]), P(outs[1]), P(outs[2]), t_out, P(w_a), P(w_s),
+    rc = lib.emu_band(int(np.log2(n)), k, pts, P(xin), t_in, P(outs[0]), P(outs[1]), P(outs[2]), t_out, P(w_a), P(w_s),
                       P(gain), 0, j_hi, 0, m_hi, blocks_per_stream, accumulate)
     assert rc == 0
     return outs

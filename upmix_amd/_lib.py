@@ -12,7 +12,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libupmix_hip.so")
+LIB_PATH = os.environ.get("UPMIX_HIP_LIB", os.path.join(_HERE, "libupmix_hip.so"))   # override: kernel experiments
 
 UPX_OK = 0
 UPX_ERR_INVALID = -1

@@ -184,44 +184,56 @@ struct Dft<16> {
 // ---------------------------------------------------------------------------
 // Static configuration per (log2 N, K = frames overlapping one sample)
 // ---------------------------------------------------------------------------
-constexpr int kP = 16;   // complex points per lane
-
-template <int LOG2N>
-struct Passes;   // radix schedule, product = N, first radix 16
-template <> struct Passes<8>  { static constexpr int n = 2; static constexpr int r[4] = {16, 16, 1, 1}; };
-template <> struct Passes<9>  { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 2, 1}; };
-template <> struct Passes<10> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 4, 1}; };
-template <> struct Passes<11> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 8, 1}; };
-template <> struct Passes<12> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 16, 1}; };
-template <> struct Passes<13> { static constexpr int n = 4; static constexpr int r[4] = {16, 16, 16, 2}; };
+// Radix schedule per (log2 N, P = complex points per lane).  Passes that go through
+// LDS are radix-P (one butterfly per lane); only the final pass may be smaller.
+template <int LOG2N, int P>
+struct Passes;
+template <> struct Passes<8, 16>  { static constexpr int n = 2; static constexpr int r[6] = {16, 16, 1, 1, 1, 1}; };
+template <> struct Passes<9, 16>  { static constexpr int n = 3; static constexpr int r[6] = {16, 16, 2, 1, 1, 1}; };
+template <> struct Passes<10, 16> { static constexpr int n = 3; static constexpr int r[6] = {16, 16, 4, 1, 1, 1}; };
+template <> struct Passes<11, 16> { static constexpr int n = 3; static constexpr int r[6] = {16, 16, 8, 1, 1, 1}; };
+template <> struct Passes<12, 16> { static constexpr int n = 3; static constexpr int r[6] = {16, 16, 16, 1, 1, 1}; };
+template <> struct Passes<13, 16> { static constexpr int n = 4; static constexpr int r[6] = {16, 16, 16, 2, 1, 1}; };
+template <> struct Passes<8, 8>   { static constexpr int n = 3; static constexpr int r[6] = {8, 8, 4, 1, 1, 1}; };
+template <> struct Passes<9, 8>   { static constexpr int n = 3; static constexpr int r[6] = {8, 8, 8, 1, 1, 1}; };
+template <> struct Passes<10, 8>  { static constexpr int n = 4; static constexpr int r[6] = {8, 8, 8, 2, 1, 1}; };
+template <> struct Passes<11, 8>  { static constexpr int n = 4; static constexpr int r[6] = {8, 8, 8, 4, 1, 1}; };
+template <> struct Passes<12, 8>  { static constexpr int n = 4; static constexpr int r[6] = {8, 8, 8, 8, 1, 1}; };
+template <> struct Passes<13, 8>  { static constexpr int n = 5; static constexpr int r[6] = {8, 8, 8, 8, 2, 1}; };
 
 constexpr int pass_ns(const int* r, int p) { return p == 0 ? 1 : r[p - 1] * pass_ns(r, p - 1); }
 // twiddle rows (each LANES entries) before pass p: sum over earlier twiddled passes of (P/R)*(R-1)
-constexpr int tw_rows_before(const int* r, int p) {
-    return p <= 1 ? 0 : (kP / r[p - 1]) * (r[p - 1] - 1) + tw_rows_before(r, p - 1);
+constexpr int tw_rows_before(const int* r, int p, int pts) {
+    return p <= 1 ? 0 : (pts / r[p - 1]) * (r[p - 1] - 1) + tw_rows_before(r, p - 1, pts);
 }
 
-template <int LOG2N_, int K_>
+template <int LOG2N_, int K_, int P_ = 16>
 struct Cfg {
     static constexpr int LOG2N = LOG2N_;
     static constexpr int N = 1 << LOG2N_;
     static constexpr int K = K_;                         // hop = N / K
+    static constexpr int P = P_;                         // complex points per lane
     static constexpr int HOP = N / K_;
-    static constexpr int LANES = N / kP;                 // lanes per stream
-    static constexpr int WG = LANES < 256 ? 256 : LANES; // threads per workgroup
+    static constexpr int LANES = N / P_;                 // lanes per stream
+    static constexpr int WG = LANES < 64 ? 64 : LANES;   // threads per workgroup (>= one wave)
     static constexpr int G = WG / LANES;                 // streams per workgroup
-    static constexpr int HS = kP / K_;                   // register slots per hop
-    static constexpr int SPITCH = LANES + LANES / 16;    // padded distance of one slot step
-    static constexpr int PITCH = N + N / 16 + 16;        // padded complex per stream buffer (+1 row: index N is addressable)
-    using PS = Passes<LOG2N_>;
-    static constexpr int TW_ROWS = tw_rows_before(PS::r, PS::n);
+    static constexpr int HS = P_ / K_;                   // register slots per hop
+    static constexpr int SPITCH = LANES + LANES / P_;    // padded distance of one slot step
+    static constexpr int PITCH = N + N / P_ + P_;        // padded complex per stream buffer (+1 row: index N is addressable)
+    static constexpr int LDS_CF = 2 * G * PITCH;         // two buffers (ping-pong): one barrier per exchange
+    static constexpr bool WAVE_SYNC = LANES <= 64;       // a stream lives inside one wave: no workgroup barrier needed
+    using PS = Passes<LOG2N_, P_>;
+    static constexpr int TW_ROWS = tw_rows_before(PS::r, PS::n, P_);
     static_assert(K_ == 2 || K_ == 4 || K_ == 8 || K_ == 16, "hop must be N/2, N/4, N/8 or N/16");
+    static_assert(P_ % K_ == 0 && P_ >= K_, "hop must be a whole number of register slots");
+    static_assert(LANES % P_ == 0 && WG <= 1024, "unsupported size");
 };
 
-// LDS index padding: one spare complex after every 16, so that the stride-16
-// scatter of the first Stockham pass (lane j writes 16 j + r) spreads over all
-// banks.  pad16(a + b) == pad16(a) + b + b/16 whenever b is a multiple of 16.
-UPX_HD int pad16(int i) { return i + (i >> 4); }
+// LDS index padding: one spare complex after every P, so that the stride-P
+// scatter of the first Stockham pass (lane j writes P j + r) spreads over all
+// banks.  padp(a + b) == padp(a) + b + b/P whenever b is a multiple of P.
+template <int P>
+UPX_HD int padp(int i) { return i + i / P; }
 
 // ---------------------------------------------------------------------------
 // Kernel arguments (one band, one launch).  Sample counts per launch are
@@ -262,19 +274,21 @@ UPX_HD void mask_bin(cf l, cf r, cf& c, cf& ls, cf& rs) {
 }
 
 // Per-thread state kept in registers across frames.
-struct Thread {
-    cf x[kP];          // FFT working set
-    float acc_l[kP];   // overlap-add state, slot s <-> sample lane + s*LANES of the current frame
-    float acc_r[kP];
-    float acc_c[kP];
-    cf cs[kP / 2];     // centre spectrum of the pair: C_a, then Yc[k]
-    cf part[kP / 2];   // Yc[N-k] of the pair
+template <int P>
+struct ThreadT {
+    cf x[P];          // FFT working set
+    float acc_l[P];   // overlap-add state, slot s <-> sample lane + s*LANES of the current frame
+    float acc_r[P];
+    float acc_c[P];
+    cf cs[P / 2];     // centre spectrum of the pair: C_a, then Yc[k]
+    cf part[P / 2];   // Yc[N-k] of the pair
 };
 
 template <class C>
 struct Stream {
-    static constexpr int N = C::N, LANES = C::LANES, P = kP;
+    static constexpr int N = C::N, LANES = C::LANES, P = C::P;
     using PS = typename C::PS;
+    using Thread = ThreadT<C::P>;
 
     // --- one Stockham pass, split at the LDS exchange ----------------------
     // inputs of butterfly q are slots q + r*(P/R); pass PI multiplies input r by
@@ -285,13 +299,18 @@ struct Stream {
         constexpr int R = PS::r[PI];
         constexpr int NS = pass_ns(PS::r, PI);
         constexpr int NB = P / R;
-        constexpr int ROW0 = tw_rows_before(PS::r, PI);
+        constexpr int ROW0 = tw_rows_before(PS::r, PI, P);
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = th.x[q + r * NB];
         if (NS > 1) {
+#if defined(UPX_EXP) && UPX_EXP >= 2   // timing experiment: no twiddle loads (wrong results)
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], mk(0.6f + 0.01f * r, 0.8f));
+#else
 #pragma unroll
             for (int r = 1; r < R; ++r)
                 v[r] = cmul(v[r], opaque(tw + (ROW0 + q * (R - 1) + (r - 1)) * LANES)[lane]);
+#endif
         }
         Dft<R>::run(v);
     }
@@ -299,14 +318,14 @@ struct Stream {
     static UPX_HD void pass_compute_write(Thread& th, cf* lds, const UPX_GLOBAL cf* tw, int lane) {
         constexpr int R = PS::r[PI];
         constexpr int NS = pass_ns(PS::r, PI);
-        static_assert(R == P, "passes that write LDS are radix-16 (one butterfly per lane)");
-        static_assert(NS == 1 || NS % 16 == 0, "padding algebra needs NS multiple of 16");
+        static_assert(R == P, "passes that write LDS are radix-P (one butterfly per lane)");
+        static_assert(NS == 1 || NS % P == 0, "padding algebra needs NS multiple of P");
         cf v[R];
         twiddle_dft<PI>(v, th, tw, lane, 0);
         const int k = lane & (NS - 1);
-        // NS == 1: 16 lane + r -> 17 lane + r ; else pad16(base) + r (NS + NS/16)
-        const int pb = NS == 1 ? lane * (R + 1) : pad16((lane - k) * R + k);
-        constexpr int STEP = NS == 1 ? 1 : NS + NS / 16;
+        // NS == 1: P lane + r -> (P+1) lane + r ; else padp(base) + r (NS + NS/P)
+        const int pb = NS == 1 ? lane * (R + 1) : padp<P>((lane - k) * R + k);
+        constexpr int STEP = NS == 1 ? 1 : NS + NS / P;
 #pragma unroll
         for (int r = 0; r < R; ++r) lds[pb + r * STEP] = v[r];
     }
@@ -324,41 +343,45 @@ struct Stream {
         }
     }
     static UPX_HD void read_all(Thread& th, const cf* lds, int lane) {
-        const cf* b = lds + pad16(lane);
+        const cf* b = lds + padp<P>(lane);
 #pragma unroll
         for (int s = 0; s < P; ++s) th.x[s] = b[s * C::SPITCH];
     }
-    // upper input slots of an inverse transform: Y[lane + s LANES], s >= P/2, parked at position idx - N/2
-    static UPX_HD void read_upper(Thread& th, const cf* lds, int lane) {
-        const cf* b = lds + pad16(lane);
-#pragma unroll
-        for (int s = P / 2; s < P; ++s) th.x[s] = b[(s - P / 2) * C::SPITCH];
-    }
-
-    // Exchanges of passes 1..n-2 plus the read that precedes the final pass:
-    //   (after W0)  R | W1 | R | ... | W(n-2) | R      ('|' = barrier)
+    // passes PI..n-2: [read rd, transform, write wr] + barrier, flipping the two buffers each time
     template <int PI, class Ex>
-    static UPX_HD void mid(Ex& ex, cf* lds_all, const cf* tw) {
-        ex.each([&](int tid, Thread& th) { read_all(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+    static UPX_HD void mid_passes(Ex& ex, cf*& rd, cf*& wr, const cf* tw) {
         if constexpr (PI < PS::n - 1) {
             ex.each([&](int tid, Thread& th) {
-                pass_compute_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, opaque(tw), tid % LANES);
+                read_all(th, rd + (tid / LANES) * C::PITCH, tid % LANES);
+                pass_compute_write<PI>(th, wr + (tid / LANES) * C::PITCH, opaque(tw), tid % LANES);
             });
-            mid<PI + 1>(ex, lds_all, tw);
+            cf* t = rd; rd = wr; wr = t;
+            mid_passes<PI + 1>(ex, rd, wr, tw);
         }
     }
 };
 
 // ---------------------------------------------------------------------------
-// The band stream program.  `ex.each(f)` = run f on every thread, then barrier.
-// Phases that write LDS are always separated by a barrier from the phase that
-// last read it (single LDS buffer per stream, 2 barriers per exchange).
+// The band stream program.  `ex.each(f)` = run f on every thread, then barrier
+// (a wave-level fence when a stream fits in one wave).  Every phase reads the
+// LDS buffer the previous phase wrote and writes the other one (ping-pong), so
+// one barrier per exchange suffices.
+//
+// Per frame pair (a, b) = (odd j, j+1), n = passes per FFT:
+//   head(a)  [load, window, pass 0]                      -> wr
+//   mid x(n-2), zsplit [final pass, park Z upper half]   -> wr
+//   mask(a)  [L/R split, gain, mask, Y mirror]           -> wr
+//   inv0     [read upper slots, pass 0], mid x(n-2)      -> wr
+//   tailLR(a) + head(b) ... same for b ...
+//   tailLR(b) + stage centre pair                        -> wr
+//   inv0, mid x(n-2);  tailC is merged into the next iteration's head(a).
 // ---------------------------------------------------------------------------
 template <class C, class Ex>
 UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     using S = Stream<C>;
     using PS = typename C::PS;
-    constexpr int N = C::N, LANES = C::LANES, P = kP, HS = C::HS, HOP = C::HOP, K = C::K;
+    using Thread = ThreadT<C::P>;
+    constexpr int N = C::N, LANES = C::LANES, P = C::P, HS = C::HS, HOP = C::HOP, K = C::K;
     constexpr int H = P / 2;        // slots holding own bins k < N/2
     constexpr int LAST = PS::n - 1; // final pass index
     constexpr int SP = C::SPITCH;
@@ -370,208 +393,274 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     const int F = a.blocks_per_stream;
     const int n_iter = (F + K + 1) / 2;   // frame pairs covering m0-(K-1) .. m0+F
 
+    cf* rd = lds_all + C::G * C::PITCH;   // buffer the previous phase wrote
+    cf* wr = lds_all;                     // buffer this phase writes
+    auto flip = [&]() { cf* t = rd; rd = wr; wr = t; };
+
+    // ---- pieces (per thread) ------------------------------------------------
+    auto head = [&](int tid, Thread& th, int it, int half) {
+        const int lane = tid % LANES;
+        const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
+        const int j = m0 - (K - 1) + 2 * it + half;
+        const int j_first = m0 - (K - 1) > a.j_lo ? m0 - (K - 1) : a.j_lo;
+        // one frame past the emitted range is still transformed: it is the pair partner of
+        // frame m0+F-1 (for even F), and pairing must not depend on how streams are cut
+        const int j_end = m0 + F + 1 < a.j_hi ? m0 + F + 1 : a.j_hi;
+        const bool exists = j >= j_first && j < j_end;
+        const int e = exists ? j * HOP + lane : 0;
+        const UPX_GLOBAL cf* in = opaque(a.in);
+        const UPX_GLOBAL float* w_a = opaque(a.w_a);
+        const int last = a.t_in - 1;   // host guarantees t_in >= 1
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            // always load an in-range sample, then zero what lies past the signal or in a
+            // frame this stream does not own (zero-extension of center_extraction.py:437-455)
+            const int n = e + s * LANES;
+#if defined(UPX_EXP) && UPX_EXP >= 4
+            const cf v = mk(0.01f * (n & 7), 0.02f);
+#else
+            const cf v = in[n < last ? n : last];
+#endif
+#if defined(UPX_EXP) && UPX_EXP >= 3
+            const float w = (exists && n <= last) ? 0.5f : 0.f;
+#else
+            const float w = (exists && n <= last) ? opaque(w_a + s * LANES)[lane] : 0.f;
+#endif
+            th.x[s] = mk(v.x * w, v.y * w);
+        }
+        S::template pass_compute_write<0>(th, wr + (tid / LANES) * C::PITCH, opaque(a.tw), lane);
+    };
+    auto tail_lr = [&](int tid, Thread& th, int it, int half) {
+        const int lane = tid % LANES;
+        S::read_all(th, rd + (tid / LANES) * C::PITCH, lane);
+        S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
+        const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
+        const int j = m0 - (K - 1) + 2 * it + half;
+        const UPX_GLOBAL float* w_s = opaque(a.w_s);
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+#if defined(UPX_EXP) && UPX_EXP >= 3
+            const float w = 0.001f;
+#else
+            const float w = opaque(w_s + s * LANES)[lane];
+#endif
+            th.acc_l[s] += th.x[s].y * w;   // swapped output: Re y = x.y, Im y = x.x
+            th.acc_r[s] += th.x[s].x * w;
+        }
+        const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
+        const bool emit = j >= m0 && j < m_end;
+        const int e = emit ? j * HOP + lane : 0;
+        UPX_GLOBAL float* out_l = opaque(a.out_l);
+        UPX_GLOBAL float* out_r = opaque(a.out_r);
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+#if defined(UPX_EXP) && UPX_EXP >= 5
+            if (emit && e + s * LANES < a.t_out && th.acc_l[s] != th.acc_l[s]) {
+#else
+            if (emit && e + s * LANES < a.t_out) {
+#endif
+                UPX_GLOBAL float* pl = opaque(out_l + s * LANES) + e;
+                UPX_GLOBAL float* pr = opaque(out_r + s * LANES) + e;
+                if (a.accumulate) {
+                    *pl += th.acc_l[s];
+                    *pr += th.acc_r[s];
+                } else {
+                    *pl = th.acc_l[s];
+                    *pr = th.acc_r[s];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            th.acc_l[s] = s + HS < P ? th.acc_l[s + HS] : 0.f;
+            th.acc_r[s] = s + HS < P ? th.acc_r[s + HS] : 0.f;
+        }
+    };
+    auto tail_c = [&](int tid, Thread& th, int it) {
+        const int lane = tid % LANES;
+        S::read_all(th, rd + (tid / LANES) * C::PITCH, lane);
+        S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
+        const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
+        const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
+        const UPX_GLOBAL float* w_s = opaque(a.w_s);
+        UPX_GLOBAL float* out_c = opaque(a.out_c);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int j = m0 - (K - 1) + 2 * it + half;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+#if defined(UPX_EXP) && UPX_EXP >= 3
+                const float w = 0.001f;
+#else
+                const float w = opaque(w_s + s * LANES)[lane];
+#endif
+                // swapped output: c_a = Re y = x.y ; c_b = Im y = x.x
+                th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w;
+            }
+            const bool emit = j >= m0 && j < m_end;
+            const int e = emit ? j * HOP + lane : 0;
+#pragma unroll
+            for (int s = 0; s < HS; ++s) {
+#if defined(UPX_EXP) && UPX_EXP >= 5
+                if (emit && e + s * LANES < a.t_out && th.acc_c[s] != th.acc_c[s]) {
+#else
+                if (emit && e + s * LANES < a.t_out) {
+#endif
+                    UPX_GLOBAL float* pc = opaque(out_c + s * LANES) + e;
+                    if (a.accumulate) *pc += th.acc_c[s];
+                    else *pc = th.acc_c[s];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
+        }
+    };
+    // passes 1..n-2, each: read what the previous phase wrote, transform, write the other buffer
+    auto mids = [&]() {
+        S::template mid_passes<1>(ex, rd, wr, a.tw);
+    };
+    // split L/R, gain, mask, build the iFFT input.  Partners Z[N-k] come from rd (natural
+    // index); the mirrored bins Y[N-k] go to wr at their natural index (N/2 = Nyquist, lane 0).
+    auto mask = [&](int tid, Thread& th, int half) {
+        const int lane = tid % LANES;
+        const UPX_GLOBAL float* gain = opaque(a.gain);
+        // k_s = lane + s LANES:  padp<P>(N - k_s) = padp<P>(N - lane - 7 LANES) + (7 - s) SP
+        const cf* zpart = rd + (tid / LANES) * C::PITCH + padp<P>(N - lane - (H - 1) * LANES);
+        cf* ymir = wr + (tid / LANES) * C::PITCH + padp<P>(N - lane - (H - 1) * LANES);
+        cf* ynyq = wr + (tid / LANES) * C::PITCH + padp<P>(N / 2);
+        cf nyq_y = mk(0.f, 0.f);
+        float nyq_c = 0.f;
+        if (lane == 0) {
+            // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
+            const float g2 = gain[N / 2];
+            const cf z = th.x[H];
+            cf l = mk(g2 * (z.x + z.x), 0.f), r = mk(g2 * (z.y + z.y), 0.f), c, ls, rs;
+            mask_bin(l, r, c, ls, rs);
+            nyq_y = mk(ls.x, rs.x);
+            nyq_c = c.x;
+        }
+#pragma unroll
+        for (int s = 0; s < H; ++s) {
+            const bool dc = s == 0 && lane == 0;   // k == 0
+#if defined(UPX_EXP) && UPX_EXP >= 3
+            const float g2 = 0.5f;
+#else
+            const float g2 = opaque(gain + s * LANES)[lane];
+#endif
+            const cf za = th.x[s];
+            const cf zp = zpart[(H - 1 - s) * SP];   // for k == 0 this is index N (spare row), unused
+            const cf zb = dc ? za : zp;              // DC pairs with itself
+            cf c = mk(0.f, 0.f), ls = c, rs = c;
+            if (g2 != 0.f) {
+                cf l = mk(g2 * (za.x + zb.x), g2 * (za.y - zb.y));   // g/2 (Z[k] + conj Z[N-k])
+                cf r = mk(g2 * (za.y + zb.y), g2 * (zb.x - za.x));   // g/2 (Z[k] - conj Z[N-k]) / i
+                mask_bin(l, r, c, ls, rs);
+            }
+            // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
+            const cf yk = mk(ls.x - rs.y, ls.y + rs.x);
+            const cf ym = mk(ls.x + rs.y, rs.x - ls.y);
+            th.x[s] = cswap(yk);
+            if (s == 0) {
+                cf* dst = lane == 0 ? ynyq : ymir + (H - 1) * SP;   // lane 0: k == 0 has no mirror; it owns Nyquist
+                *dst = cswap(lane == 0 ? nyq_y : ym);
+            } else {
+                ymir[(H - 1 - s) * SP] = cswap(ym);
+            }
+            // centre spectrum; lane 0 slot 0 packs the two real bins (DC, Nyquist)
+            const cf cv = dc ? mk(c.x, nyq_c) : c;
+            if (half == 0) {
+                th.cs[s] = cv;
+            } else {
+                const cf ca = th.cs[s], cb = cv;
+                // Yc[k] = Ca + i Cb ; Yc[N-k] = conj(Ca) + i conj(Cb)
+                cf ck = mk(ca.x - cb.y, ca.y + cb.x);
+                cf cm = mk(ca.x + cb.y, cb.x - ca.y);
+                if (dc) {
+                    ck = mk(ca.x, cb.x);   // Yc[0]
+                    cm = mk(ca.y, cb.y);   // Yc[N/2]
+                }
+                th.cs[s] = cswap(ck);
+                th.part[s] = cswap(cm);
+            }
+        }
+    };
+    // first inverse pass: slots >= H hold Y[lane + s LANES] (natural index) written by the other lanes
+    auto inv0 = [&](int tid, Thread& th) {
+        const int lane = tid % LANES;
+        const cf* b = rd + (tid / LANES) * C::PITCH + padp<P>(lane);
+#pragma unroll
+        for (int s = H; s < P; ++s) th.x[s] = b[s * SP];
+        S::template pass_compute_write<0>(th, wr + (tid / LANES) * C::PITCH, opaque(a.tw), lane);
+    };
+    auto zsplit = [&](int tid, Thread& th) {
+        const int lane = tid % LANES;
+        S::read_all(th, rd + (tid / LANES) * C::PITCH, lane);
+        S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
+        cf* b = wr + (tid / LANES) * C::PITCH + padp<P>(lane);
+#pragma unroll
+        for (int s = H; s < P; ++s) b[s * SP] = th.x[s];
+    };
+    auto stage_c = [&](int tid, Thread& th) {
+        const int lane = tid % LANES;
+        cf* ymir = wr + (tid / LANES) * C::PITCH + padp<P>(N - lane - (H - 1) * LANES);
+        cf* ynyq = wr + (tid / LANES) * C::PITCH + padp<P>(N / 2);
+#pragma unroll
+        for (int s = 0; s < H; ++s) {
+            th.x[s] = th.cs[s];
+            if (s == 0) {
+                cf* dst = lane == 0 ? ynyq : ymir + (H - 1) * SP;
+                *dst = th.part[0];
+            } else {
+                ymir[(H - 1 - s) * SP] = th.part[s];
+            }
+        }
+    };
+
     ex.each([&](int, Thread& th) {
 #pragma unroll
         for (int s = 0; s < P; ++s) th.acc_l[s] = th.acc_r[s] = th.acc_c[s] = 0.f;
     });
 
     for (int it = 0; it < n_iter; ++it) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            // ---- load + window + forward pass 0 --------------------------
-            ex.each([&](int tid, Thread& th) {
-                const int lane = tid % LANES;
-                const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
-                const int j = m0 - (K - 1) + 2 * it + half;
-                const int j_first = m0 - (K - 1) > a.j_lo ? m0 - (K - 1) : a.j_lo;
-                // one frame past the emitted range is still transformed: it is the pair partner of
-                // frame m0+F-1 (for even F), and pairing must not depend on how streams are cut
-                const int j_end = m0 + F + 1 < a.j_hi ? m0 + F + 1 : a.j_hi;
-                const bool exists = j >= j_first && j < j_end;
-                const int e = exists ? j * HOP + lane : 0;
-                const UPX_GLOBAL cf* in = opaque(a.in);
-                const UPX_GLOBAL float* w_a = opaque(a.w_a);
-                const int last = a.t_in - 1;   // host guarantees t_in >= 1
-#pragma unroll
-                for (int s = 0; s < P; ++s) {
-                    // always load an in-range sample, then zero what lies past the signal or in a
-                    // frame this stream does not own (zero-extension of center_extraction.py:437-455)
-                    const int n = e + s * LANES;
-                    const cf v = in[n < last ? n : last];
-                    const float w = (exists && n <= last) ? opaque(w_a + s * LANES)[lane] : 0.f;
-                    th.x[s] = mk(v.x * w, v.y * w);
-                }
-                S::template pass_compute_write<0>(th, lds_all + (tid / LANES) * C::PITCH, opaque(a.tw), lane);
-            });
-            S::template mid<1>(ex, lds_all, a.tw);
-            // ---- forward final pass; park the upper half Z[N/2..N) in LDS --
-            ex.each([&](int tid, Thread& th) {
-                const int lane = tid % LANES;
-                cf* b = lds_all + (tid / LANES) * C::PITCH + pad16(lane);
-                S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
-#pragma unroll
-                for (int s = H; s < P; ++s) b[s * SP] = th.x[s];
-            });
-            // ---- split L/R, gain, mask, build iFFT input -----------------
-            // partners Z[N-k] come from the upper region; Y[N-k] goes to the lower
-            // region at position (N-k) - N/2 (position 0 = Nyquist, written by lane 0).
-            ex.each([&](int tid, Thread& th) {
-                cf* lds = lds_all + (tid / LANES) * C::PITCH;
-                const int lane = tid % LANES;
-                const UPX_GLOBAL float* gain = opaque(a.gain);
-                // k_s = lane + s LANES:  pad16(N - k_s) = pad16(N - lane - 7 LANES) + (7 - s) SP  (SP covers LANES, a multiple of 16)
-                const cf* zpart = lds + pad16(N - lane - (H - 1) * LANES);
-                cf* ymir = lds + pad16(N / 2 - lane - (H - 1) * LANES);
-                cf nyq_y = mk(0.f, 0.f);
-                float nyq_c = 0.f;
-                if (lane == 0) {
-                    // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
-                    const float g2 = gain[N / 2];
-                    const cf z = th.x[H];
-                    cf l = mk(g2 * (z.x + z.x), 0.f), r = mk(g2 * (z.y + z.y), 0.f), c, ls, rs;
-                    mask_bin(l, r, c, ls, rs);
-                    nyq_y = mk(ls.x, rs.x);
-                    nyq_c = c.x;
-                }
-#pragma unroll
-                for (int s = 0; s < H; ++s) {
-                    const bool dc = s == 0 && lane == 0;   // k == 0
-                    const float g2 = opaque(gain + s * LANES)[lane];
-                    const cf za = th.x[s];
-                    const cf zp = zpart[(H - 1 - s) * SP];   // for k == 0 this is index N (spare row), unused
-                    const cf zb = dc ? za : zp;              // DC pairs with itself
-                    cf c = mk(0.f, 0.f), ls = c, rs = c;
-                    if (g2 != 0.f) {
-                        cf l = mk(g2 * (za.x + zb.x), g2 * (za.y - zb.y));   // g/2 (Z[k] + conj Z[N-k])
-                        cf r = mk(g2 * (za.y + zb.y), g2 * (zb.x - za.x));   // g/2 (Z[k] - conj Z[N-k]) / i
-                        mask_bin(l, r, c, ls, rs);
-                    }
-                    // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
-                    const cf yk = mk(ls.x - rs.y, ls.y + rs.x);
-                    const cf ym = mk(ls.x + rs.y, rs.x - ls.y);
-                    th.x[s] = cswap(yk);
-                    if (s == 0) {
-                        cf* dst = lane == 0 ? lds : ymir + (H - 1) * SP;   // lane 0: Nyquist at position 0
-                        *dst = cswap(lane == 0 ? nyq_y : ym);
-                    } else {
-                        ymir[(H - 1 - s) * SP] = cswap(ym);
-                    }
-                    // centre spectrum; lane 0 slot 0 packs the two real bins (DC, Nyquist)
-                    const cf cv = dc ? mk(c.x, nyq_c) : c;
-                    if (half == 0) {
-                        th.cs[s] = cv;
-                    } else {
-                        const cf ca = th.cs[s], cb = cv;
-                        // Yc[k] = Ca + i Cb ; Yc[N-k] = conj(Ca) + i conj(Cb)
-                        cf ck = mk(ca.x - cb.y, ca.y + cb.x);
-                        cf cm = mk(ca.x + cb.y, cb.x - ca.y);
-                        if (dc) {
-                            ck = mk(ca.x, cb.x);   // Yc[0]
-                            cm = mk(ca.y, cb.y);   // Yc[N/2]
-                        }
-                        th.cs[s] = cswap(ck);
-                        th.part[s] = cswap(cm);
-                    }
-                }
-            });
-            // ---- upper iFFT input slots come from the lower region -------
-            ex.each([&](int tid, Thread& th) { S::read_upper(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
-            // ---- inverse FFT of Ls + i Rs --------------------------------
-            ex.each([&](int tid, Thread& th) {
-                S::template pass_compute_write<0>(th, lds_all + (tid / LANES) * C::PITCH, opaque(a.tw), tid % LANES);
-            });
-            S::template mid<1>(ex, lds_all, a.tw);
-            // ---- final pass, window, overlap-add, emit L/R hop; stage centre pair
-            ex.each([&](int tid, Thread& th) {
-                cf* lds = lds_all + (tid / LANES) * C::PITCH;
-                const int lane = tid % LANES;
-                S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
-                const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
-                const int j = m0 - (K - 1) + 2 * it + half;
-                const UPX_GLOBAL float* w_s = opaque(a.w_s);
-#pragma unroll
-                for (int s = 0; s < P; ++s) {
-                    const float w = opaque(w_s + s * LANES)[lane];
-                    th.acc_l[s] += th.x[s].y * w;   // swapped output: Re y = x.y, Im y = x.x
-                    th.acc_r[s] += th.x[s].x * w;
-                }
-                const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
-                const bool emit = j >= m0 && j < m_end;
-                const int e = emit ? j * HOP + lane : 0;
-                UPX_GLOBAL float* out_l = opaque(a.out_l);
-                UPX_GLOBAL float* out_r = opaque(a.out_r);
-#pragma unroll
-                for (int s = 0; s < HS; ++s) {
-                    if (emit && e + s * LANES < a.t_out) {
-                        UPX_GLOBAL float* pl = opaque(out_l + s * LANES) + e;
-                        UPX_GLOBAL float* pr = opaque(out_r + s * LANES) + e;
-                        if (a.accumulate) {
-                            *pl += th.acc_l[s];
-                            *pr += th.acc_r[s];
-                        } else {
-                            *pl = th.acc_l[s];
-                            *pr = th.acc_r[s];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < P; ++s) {
-                    th.acc_l[s] = s + HS < P ? th.acc_l[s + HS] : 0.f;
-                    th.acc_r[s] = s + HS < P ? th.acc_r[s + HS] : 0.f;
-                }
-                if (half == 1) {
-                    // centre pair: own bins to registers, mirrored bins to the lower region
-                    cf* ymir = lds + pad16(N / 2 - lane - (H - 1) * LANES);
-#pragma unroll
-                    for (int s = 0; s < H; ++s) {
-                        th.x[s] = th.cs[s];
-                        if (s == 0) {
-                            cf* dst = lane == 0 ? lds : ymir + (H - 1) * SP;
-                            *dst = th.part[0];
-                        } else {
-                            ymir[(H - 1 - s) * SP] = th.part[s];
-                        }
-                    }
-                }
-            });
-        }
-        // ---- centre pair: iFFT of Ca + i Cb ------------------------------
-        ex.each([&](int tid, Thread& th) { S::read_upper(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+        // ---- frame a ----------------------------------------------------------
         ex.each([&](int tid, Thread& th) {
-            S::template pass_compute_write<0>(th, lds_all + (tid / LANES) * C::PITCH, opaque(a.tw), tid % LANES);
+            if (it > 0) tail_c(tid, th, it - 1);
+            head(tid, th, it, 0);
         });
-        S::template mid<1>(ex, lds_all, a.tw);
+        flip();
+        mids();
+        ex.each([&](int tid, Thread& th) { zsplit(tid, th); });
+        flip();
+        ex.each([&](int tid, Thread& th) { mask(tid, th, 0); });
+        flip();
+        ex.each([&](int tid, Thread& th) { inv0(tid, th); });
+        flip();
+        mids();
+        // ---- frame b ----------------------------------------------------------
         ex.each([&](int tid, Thread& th) {
-            const int lane = tid % LANES;
-            S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
-            const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
-            const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
-            const UPX_GLOBAL float* w_s = opaque(a.w_s);
-            UPX_GLOBAL float* out_c = opaque(a.out_c);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int j = m0 - (K - 1) + 2 * it + half;
-#pragma unroll
-                for (int s = 0; s < P; ++s) {
-                    const float w = opaque(w_s + s * LANES)[lane];
-                    // swapped output: c_a = Re y = x.y ; c_b = Im y = x.x
-                    th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w;
-                }
-                const bool emit = j >= m0 && j < m_end;
-                const int e = emit ? j * HOP + lane : 0;
-#pragma unroll
-                for (int s = 0; s < HS; ++s) {
-                    if (emit && e + s * LANES < a.t_out) {
-                        UPX_GLOBAL float* pc = opaque(out_c + s * LANES) + e;
-                        if (a.accumulate) *pc += th.acc_c[s];
-                        else *pc = th.acc_c[s];
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
-            }
+            tail_lr(tid, th, it, 0);
+            head(tid, th, it, 1);
         });
+        flip();
+        mids();
+        ex.each([&](int tid, Thread& th) { zsplit(tid, th); });
+        flip();
+        ex.each([&](int tid, Thread& th) { mask(tid, th, 1); });
+        flip();
+        ex.each([&](int tid, Thread& th) { inv0(tid, th); });
+        flip();
+        mids();
+        // ---- centre pair ------------------------------------------------------
+        ex.each([&](int tid, Thread& th) {
+            tail_lr(tid, th, it, 1);
+            stage_c(tid, th);
+        });
+        flip();
+        ex.each([&](int tid, Thread& th) { inv0(tid, th); });
+        flip();
+        mids();
     }
+    ex.each([&](int tid, Thread& th) { tail_c(tid, th, n_iter - 1); });
 }
 
 // Host-side helper: fill the twiddle table for Cfg (double precision -> float).
@@ -579,7 +668,7 @@ template <class C, class TrigFn>
 inline void fill_twiddles(cf* tw, TrigFn trig) {
     using PS = typename C::PS;
     for (int p = 1; p < PS::n; ++p) {
-        const int R = PS::r[p], NS = pass_ns(PS::r, p), NB = kP / R, row0 = tw_rows_before(PS::r, p);
+        const int R = PS::r[p], NS = pass_ns(PS::r, p), NB = C::P / R, row0 = tw_rows_before(PS::r, p, C::P);
         for (int q = 0; q < NB; ++q)
             for (int r = 1; r < R; ++r)
                 for (int lane = 0; lane < C::LANES; ++lane) {

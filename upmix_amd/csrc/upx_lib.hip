@@ -43,12 +43,26 @@ int fail(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
+// `each` = the calling thread runs the phase, then synchronises with the other lanes of its
+// stream: a workgroup barrier, or - when a stream lives inside one wave - only a
+// wavefront-scope fence (LDS operations of one wave execute in order).
+template <bool WAVE_SYNC, int P>
 struct DevExec {
-    upx::Thread st;
+    upx::ThreadT<P> st;
     template <class F>
     __device__ __forceinline__ void each(F&& f) {
         f((int)threadIdx.x, st);
-        __syncthreads();
+#if defined(UPX_EXP) && UPX_EXP >= 6
+        if constexpr (true) {   // timing experiment: no workgroup barriers at all (wrong results)
+#else
+        if constexpr (WAVE_SYNC) {
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
     }
 };
 
@@ -56,7 +70,7 @@ struct DevExec {
 template <class C, int WPE>
 __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec ex;
+    DevExec<C::WAVE_SYNC, C::P> ex;
     upx::band_program<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 
@@ -109,7 +123,7 @@ void turn_trig(double frac, double& c, double& s) {
 
 template <class C, int WPE>
 struct Entry {
-    static constexpr int kLds = C::G * C::PITCH * (int)sizeof(upx::cf);
+    static constexpr int kLds = C::LDS_CF * (int)sizeof(upx::cf);
     static void launch(const upx::BandArgs& a, int n_wg, hipStream_t st) {
         hipLaunchKernelGGL((upx_band_kernel<C, WPE>), dim3(n_wg), dim3(C::WG), kLds, st, a);
     }
@@ -123,27 +137,32 @@ struct Entry {
     }
 };
 
-// (log2 N, K, variant) -> kernel.  K = N / hop.  Variant 0 is the default build
-// (2 waves/SIMD register budget); variant 1 (hop = N/4 only) trades a few
-// scratch spills for 3 waves/SIMD and is selected with UPX_KERNEL_VARIANT=1.
-const KernelEntry* find_kernel(int log2n, int k, int variant = 0) {
+// (log2 N, K, variant) -> kernel.  K = N / hop.
+//   variant 0: 16 points per lane, register budget for 2 waves/SIMD (256 VGPRs)
+//   variant 1:  8 points per lane, register budget for 4 waves/SIMD (128 VGPRs)
+// UPX_KERNEL_VARIANT selects; the default is set in default_variant().
+const KernelEntry* find_kernel(int log2n, int k, int variant) {
     static const std::map<std::tuple<int, int, int>, KernelEntry> table = [] {
         std::map<std::tuple<int, int, int>, KernelEntry> t;
-#define UPX_REG(L, K, W, V) t[std::make_tuple(L, K, V)] = Entry<upx::Cfg<L, K>, W>::get("upx_band_kernel<Cfg<" #L "," #K ">," #W ">");
-        UPX_REG(8, 2, 2, 0) UPX_REG(8, 4, 2, 0) UPX_REG(8, 8, 2, 0)
-        UPX_REG(9, 2, 2, 0) UPX_REG(9, 4, 2, 0) UPX_REG(9, 8, 2, 0)
-        UPX_REG(10, 2, 2, 0) UPX_REG(10, 4, 2, 0) UPX_REG(10, 8, 2, 0)
-        UPX_REG(11, 2, 2, 0) UPX_REG(11, 4, 2, 0) UPX_REG(11, 8, 2, 0)
-        UPX_REG(12, 2, 2, 0) UPX_REG(12, 4, 2, 0) UPX_REG(12, 8, 2, 0)
-        UPX_REG(13, 2, 2, 0) UPX_REG(13, 4, 2, 0) UPX_REG(13, 8, 2, 0)
-        UPX_REG(8, 4, 3, 1) UPX_REG(9, 4, 3, 1) UPX_REG(10, 4, 3, 1) UPX_REG(11, 4, 3, 1) UPX_REG(12, 4, 3, 1)
-        UPX_REG(13, 4, 4, 1)
+#define UPX_REG(L, K, PP, W, V) \
+    t[std::make_tuple(L, K, V)] = Entry<upx::Cfg<L, K, PP>, W>::get("upx_band_kernel<Cfg<" #L "," #K "," #PP ">," #W ">");
+#define UPX_REG_SIZES(K, PP, W, V) \
+    UPX_REG(8, K, PP, W, V) UPX_REG(9, K, PP, W, V) UPX_REG(10, K, PP, W, V) UPX_REG(11, K, PP, W, V) \
+    UPX_REG(12, K, PP, W, V) UPX_REG(13, K, PP, W, V)
+        UPX_REG_SIZES(2, 16, 2, 0) UPX_REG_SIZES(4, 16, 2, 0) UPX_REG_SIZES(8, 16, 2, 0)
+        UPX_REG_SIZES(2, 8, 4, 1) UPX_REG_SIZES(4, 8, 4, 1) UPX_REG_SIZES(8, 8, 4, 1)
+#undef UPX_REG_SIZES
 #undef UPX_REG
         return t;
     }();
     auto it = table.find(std::make_tuple(log2n, k, variant));
     if (it == table.end() && variant != 0) it = table.find(std::make_tuple(log2n, k, 0));
     return it == table.end() ? nullptr : &it->second;
+}
+
+int default_variant() {
+    const char* v = std::getenv("UPX_KERNEL_VARIANT");
+    return v ? std::atoi(v) : 0;
 }
 
 int ilog2_exact(int v) {
@@ -257,7 +276,7 @@ int upx_supported(int32_t block_size, int32_t hop) {
     if (block_size < 1 || hop < 1 || block_size % hop) return 0;
     const int l = ilog2_exact(block_size);
     if (l < 0) return 0;
-    return find_kernel(l, block_size / hop) ? 1 : 0;
+    return find_kernel(l, block_size / hop, 0) ? 1 : 0;
 }
 
 int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* block_size, const int32_t* hop,
@@ -291,10 +310,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         s.hop = hop[b];
         s.k = s.n / s.hop;
         s.log2n = ilog2_exact(s.n);
-        {
-            const char* v = std::getenv("UPX_KERNEL_VARIANT");
-            s.kern = find_kernel(s.log2n, s.k, v ? std::atoi(v) : 0);
-        }
+        s.kern = find_kernel(s.log2n, s.k, default_variant());
         if (int e = s.kern->prepare()) {
             upx_plan_destroy(p);
             return fail(UPX_ERR_HIP, "hipFuncSetAttribute(%s): %s", s.kern->name, hipGetErrorString((hipError_t)e));
@@ -309,7 +325,8 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         HIP_TRY(hipMemcpy(s.d_wa, w_analysis + off_w, s.n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.d_ws, ws.data(), s.n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.d_gain, gh.data(), nb * sizeof(float), hipMemcpyHostToDevice));
-        auto it = p->tw.find(s.log2n);
+        const int tw_key = s.log2n * 100000 + s.kern->lanes;   // layout depends on points per lane
+        auto it = p->tw.find(tw_key);
         if (it == p->tw.end()) {
             const size_t cnt = (size_t)(s.kern->tw_rows > 0 ? s.kern->tw_rows : 1) * s.kern->lanes;
             std::vector<upx::cf> host(cnt);
@@ -317,7 +334,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             upx::cf* d = nullptr;
             HIP_TRY(hipMalloc(&d, cnt * sizeof(upx::cf)));
             HIP_TRY(hipMemcpy(d, host.data(), cnt * sizeof(upx::cf), hipMemcpyHostToDevice));
-            it = p->tw.emplace(s.log2n, d).first;
+            it = p->tw.emplace(tw_key, d).first;
         }
         s.d_tw = it->second;
         HIP_TRY(hipEventCreate(&s.ev0));
@@ -413,7 +430,10 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         if (j_hi > 0x7fffffffLL || m_all > 0x7fffffffLL) return fail(UPX_ERR_INVALID, "signal too long for int32 frame index");
         if (m_hi <= 0) continue;
         // blocks per stream: fill every resident workgroup slot once, never fewer than 8 blocks
-        const int resident = (s.kern->wpe * 256) / s.kern->wg > 0 ? (s.kern->wpe * 256) / s.kern->wg : 1;   // workgroups per CU
+        int resident = (s.kern->wpe * 256) / s.kern->wg;              // workgroups per CU by registers
+        const int by_lds = (160 * 1024) / s.kern->lds_bytes;              // ... and by LDS
+        if (resident > by_lds) resident = by_lds;
+        if (resident < 1) resident = 1;
         long long target_streams = (long long)p->n_cu * resident * s.kern->g;
         long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + target_streams - 1) / target_streams;
         if (s.blocks_override <= 0 && f < 8) f = 8;
