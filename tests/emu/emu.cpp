@@ -28,7 +28,7 @@ void turn_trig(double frac, double& c, double& s) {
 
 template <class C>
 int run(upx::BandArgs a) {
-    std::vector<upx::cf> tw((size_t)(C::TW_ROWS > 0 ? C::TW_ROWS : 1) * C::LANES);
+    std::vector<upx::cf> tw((size_t)C::TW_CF);
     upx::fill_twiddles<C>(tw.data(), turn_trig);
     a.tw = tw.data();
     const long long n_blocks = (long long)a.m_hi - a.m_lo;

@@ -202,9 +202,9 @@ template <> struct Passes<12, 8>  { static constexpr int n = 4; static constexpr
 template <> struct Passes<13, 8>  { static constexpr int n = 5; static constexpr int r[6] = {8, 8, 8, 8, 2, 1}; };
 
 constexpr int pass_ns(const int* r, int p) { return p == 0 ? 1 : r[p - 1] * pass_ns(r, p - 1); }
-// twiddle rows (each LANES entries) before pass p: sum over earlier twiddled passes of (P/R)*(R-1)
-constexpr int tw_rows_before(const int* r, int p, int pts) {
-    return p <= 1 ? 0 : (pts / r[p - 1]) * (r[p - 1] - 1) + tw_rows_before(r, p - 1, pts);
+// offset (in complex) of pass p's rows in the compact twiddle table: passes 1..p-1 hold (R-1) rows of NS entries
+constexpr int tw_offset(const int* r, int p) {
+    return p <= 1 ? 0 : (r[p - 1] - 1) * pass_ns(r, p - 1) + tw_offset(r, p - 1);
 }
 
 template <int LOG2N_, int K_, int P_ = 16>
@@ -220,10 +220,10 @@ struct Cfg {
     static constexpr int HS = P_ / K_;                   // register slots per hop
     static constexpr int SPITCH = LANES + LANES / P_;    // padded distance of one slot step
     static constexpr int PITCH = N + N / P_ + P_;        // padded complex per stream buffer (+1 row: index N is addressable)
-    static constexpr int LDS_CF = 2 * G * PITCH;         // two buffers (ping-pong): one barrier per exchange
-    static constexpr bool WAVE_SYNC = LANES <= 64;       // a stream lives inside one wave: no workgroup barrier needed
     using PS = Passes<LOG2N_, P_>;
-    static constexpr int TW_ROWS = tw_rows_before(PS::r, PS::n, P_);
+    static constexpr int TW_CF = tw_offset(PS::r, PS::n) > 0 ? tw_offset(PS::r, PS::n) : 1;   // twiddle table entries
+    static constexpr int LDS_CF = G * PITCH + TW_CF;     // stream buffers + twiddle table
+    static constexpr bool WAVE_SYNC = LANES <= 64;       // a stream lives inside one wave: no workgroup barrier needed
     static_assert(K_ == 2 || K_ == 4 || K_ == 8 || K_ == 16, "hop must be N/2, N/4, N/8 or N/16");
     static_assert(P_ % K_ == 0 && P_ >= K_, "hop must be a whole number of register slots");
     static_assert(LANES % P_ == 0 && WG <= 1024, "unsupported size");
@@ -290,91 +290,83 @@ struct Stream {
     using PS = typename C::PS;
     using Thread = ThreadT<C::P>;
 
-    // --- one Stockham pass, split at the LDS exchange ----------------------
+    // --- one Stockham pass ---------------------------------------------------
     // inputs of butterfly q are slots q + r*(P/R); pass PI multiplies input r by
-    // W_(NS*R)^(r*k), k = j mod NS, then a radix-R DFT; output r goes to
-    // (j - k) R + k + r NS.
+    // W_(NS*R)^(r*k), k = j mod NS (j = lane + q LANES), then a radix-R DFT in place;
+    // output r belongs at (j - k) R + k + r NS.  Twiddles come from the LDS table
+    // tw[row(PI, r)][k] (compact: NS entries per row).
     template <int PI>
-    static UPX_HD void twiddle_dft(cf (&v)[PS::r[PI]], const Thread& th, const UPX_GLOBAL cf* tw, int lane, int q) {
+    static UPX_HD void pass_compute(Thread& th, const cf* tw, int lane) {
         constexpr int R = PS::r[PI];
         constexpr int NS = pass_ns(PS::r, PI);
         constexpr int NB = P / R;
-        constexpr int ROW0 = tw_rows_before(PS::r, PI, P);
-#pragma unroll
-        for (int r = 0; r < R; ++r) v[r] = th.x[q + r * NB];
-        if (NS > 1) {
-#if defined(UPX_EXP) && UPX_EXP >= 2   // timing experiment: no twiddle loads (wrong results)
-#pragma unroll
-            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], mk(0.6f + 0.01f * r, 0.8f));
-#else
-#pragma unroll
-            for (int r = 1; r < R; ++r)
-                v[r] = cmul(v[r], opaque(tw + (ROW0 + q * (R - 1) + (r - 1)) * LANES)[lane]);
-#endif
-        }
-        Dft<R>::run(v);
-    }
-    template <int PI>
-    static UPX_HD void pass_compute_write(Thread& th, cf* lds, const UPX_GLOBAL cf* tw, int lane) {
-        constexpr int R = PS::r[PI];
-        constexpr int NS = pass_ns(PS::r, PI);
-        static_assert(R == P, "passes that write LDS are radix-P (one butterfly per lane)");
-        static_assert(NS == 1 || NS % P == 0, "padding algebra needs NS multiple of P");
-        cf v[R];
-        twiddle_dft<PI>(v, th, tw, lane, 0);
-        const int k = lane & (NS - 1);
-        // NS == 1: P lane + r -> (P+1) lane + r ; else padp(base) + r (NS + NS/P)
-        const int pb = NS == 1 ? lane * (R + 1) : padp<P>((lane - k) * R + k);
-        constexpr int STEP = NS == 1 ? 1 : NS + NS / P;
-#pragma unroll
-        for (int r = 0; r < R; ++r) lds[pb + r * STEP] = v[r];
-    }
-    // last pass: results stay in registers in natural slot order
-    template <int PI>
-    static UPX_HD void pass_compute_final(Thread& th, const UPX_GLOBAL cf* tw, int lane) {
-        constexpr int R = PS::r[PI];
-        constexpr int NB = P / R;
+        constexpr int OFF = tw_offset(PS::r, PI);
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             cf v[R];
-            twiddle_dft<PI>(v, th, tw, lane, q);
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = th.x[q + r * NB];
+            if (NS > 1) {
+                const cf* row = tw + OFF + ((lane + q * LANES) & (NS - 1));
+#pragma unroll
+                for (int r = 1; r < R; ++r) v[r] = cmul(v[r], row[(r - 1) * NS]);
+            }
+            Dft<R>::run(v);
 #pragma unroll
             for (int r = 0; r < R; ++r) th.x[q + r * NB] = v[r];
         }
+    }
+    // scatter of a radix-P pass (one butterfly per lane): slot r -> (lane - k) P + k + r NS
+    template <int PI>
+    static UPX_HD void pass_write(const Thread& th, cf* lds, int lane) {
+        constexpr int R = PS::r[PI];
+        constexpr int NS = pass_ns(PS::r, PI);
+        static_assert(R == P, "passes that go through LDS are radix-P (one butterfly per lane)");
+        static_assert(NS == 1 || NS % P == 0, "padding algebra needs NS multiple of P");
+        const int k = lane & (NS - 1);
+        // NS == 1: P lane + r -> (P+1) lane + r ; else padp(base) + r (NS + NS/P)
+        cf* b = lds + (NS == 1 ? lane * (R + 1) : padp<P>((lane - k) * R + k));
+        constexpr int STEP = NS == 1 ? 1 : NS + NS / P;
+#pragma unroll
+        for (int r = 0; r < R; ++r) b[r * STEP] = th.x[r];
     }
     static UPX_HD void read_all(Thread& th, const cf* lds, int lane) {
         const cf* b = lds + padp<P>(lane);
 #pragma unroll
         for (int s = 0; s < P; ++s) th.x[s] = b[s * C::SPITCH];
     }
-    // passes PI..n-2: [read rd, transform, write wr] + barrier, flipping the two buffers each time
+
+    // passes PI..n-2:  [read, transform] | [scatter] |   ('|' = barrier)
     template <int PI, class Ex>
-    static UPX_HD void mid_passes(Ex& ex, cf*& rd, cf*& wr, const cf* tw) {
+    static UPX_HD void mid_passes(Ex& ex, cf* lds_all, const cf* tw) {
         if constexpr (PI < PS::n - 1) {
             ex.each([&](int tid, Thread& th) {
-                read_all(th, rd + (tid / LANES) * C::PITCH, tid % LANES);
-                pass_compute_write<PI>(th, wr + (tid / LANES) * C::PITCH, opaque(tw), tid % LANES);
+                read_all(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES);
+                pass_compute<PI>(th, tw, tid % LANES);
             });
-            cf* t = rd; rd = wr; wr = t;
-            mid_passes<PI + 1>(ex, rd, wr, tw);
+            ex.each([&](int tid, Thread& th) { pass_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+            mid_passes<PI + 1>(ex, lds_all, tw);
         }
     }
 };
 
 // ---------------------------------------------------------------------------
 // The band stream program.  `ex.each(f)` = run f on every thread, then barrier
-// (a wave-level fence when a stream fits in one wave).  Every phase reads the
-// LDS buffer the previous phase wrote and writes the other one (ping-pong), so
-// one barrier per exchange suffices.
+// (a wave-level fence when a stream fits in one wave).  One LDS buffer per
+// stream: a phase that scatters into it is separated by a barrier from the phase
+// that last read it.  The inter-pass twiddles live in LDS (copied once per
+// workgroup), so the per-frame global traffic is the audio itself plus the
+// window / gain vectors.
 //
 // Per frame pair (a, b) = (odd j, j+1), n = passes per FFT:
-//   head(a)  [load, window, pass 0]                      -> wr
-//   mid x(n-2), zsplit [final pass, park Z upper half]   -> wr
-//   mask(a)  [L/R split, gain, mask, Y mirror]           -> wr
-//   inv0     [read upper slots, pass 0], mid x(n-2)      -> wr
-//   tailLR(a) + head(b) ... same for b ...
-//   tailLR(b) + stage centre pair                        -> wr
-//   inv0, mid x(n-2);  tailC is merged into the next iteration's head(a).
+//   head(a)   load, window, pass 0                      | scatter |
+//   mid       (read, pass p | scatter |) x (n-2)
+//   zsplit    read, final pass | park Z[N/2..N) |
+//   mask(a)   partners from the upper region, L/R split, gain, mask; Y mirror -> lower region |
+//   inv0      read upper slots, pass 0 | scatter |  mid ...
+//   tailLR(a) read, final pass, window, overlap-add, emit hop; then head(b) ...
+//   tailLR(b), then stage the centre pair | mirror -> lower region | inv0 ... mid
+//   tailC is merged into the next iteration's head(a).
 // ---------------------------------------------------------------------------
 template <class C, class Ex>
 UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
@@ -393,9 +385,13 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     const int F = a.blocks_per_stream;
     const int n_iter = (F + K + 1) / 2;   // frame pairs covering m0-(K-1) .. m0+F
 
-    cf* rd = lds_all + C::G * C::PITCH;   // buffer the previous phase wrote
-    cf* wr = lds_all;                     // buffer this phase writes
-    auto flip = [&]() { cf* t = rd; rd = wr; wr = t; };
+    cf* const tw = lds_all + C::G * C::PITCH;   // LDS twiddle table, after the stream buffers
+
+    // ---- copy the twiddle table into LDS ------------------------------------
+    ex.each([&](int tid, Thread&) {
+        const UPX_GLOBAL cf* src = opaque(a.tw);
+        for (int i = tid; i < C::TW_CF; i += C::WG) tw[i] = src[i];
+    });
 
     // ---- pieces (per thread) ------------------------------------------------
     auto head = [&](int tid, Thread& th, int it, int half) {
@@ -416,58 +412,47 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             // always load an in-range sample, then zero what lies past the signal or in a
             // frame this stream does not own (zero-extension of center_extraction.py:437-455)
             const int n = e + s * LANES;
-#if defined(UPX_EXP) && UPX_EXP >= 4
-            const cf v = mk(0.01f * (n & 7), 0.02f);
-#else
             const cf v = in[n < last ? n : last];
-#endif
-#if defined(UPX_EXP) && UPX_EXP >= 3
-            const float w = (exists && n <= last) ? 0.5f : 0.f;
-#else
             const float w = (exists && n <= last) ? opaque(w_a + s * LANES)[lane] : 0.f;
-#endif
             th.x[s] = mk(v.x * w, v.y * w);
         }
-        S::template pass_compute_write<0>(th, wr + (tid / LANES) * C::PITCH, opaque(a.tw), lane);
+        S::template pass_compute<0>(th, tw, lane);
     };
+    // read-modify-write of one emitted hop: the old values are fetched BEFORE the final pass
+    // so that their HBM latency overlaps the butterflies
     auto tail_lr = [&](int tid, Thread& th, int it, int half) {
         const int lane = tid % LANES;
-        S::read_all(th, rd + (tid / LANES) * C::PITCH, lane);
-        S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
         const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
         const int j = m0 - (K - 1) + 2 * it + half;
-        const UPX_GLOBAL float* w_s = opaque(a.w_s);
-#pragma unroll
-        for (int s = 0; s < P; ++s) {
-#if defined(UPX_EXP) && UPX_EXP >= 3
-            const float w = 0.001f;
-#else
-            const float w = opaque(w_s + s * LANES)[lane];
-#endif
-            th.acc_l[s] += th.x[s].y * w;   // swapped output: Re y = x.y, Im y = x.x
-            th.acc_r[s] += th.x[s].x * w;
-        }
         const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
         const bool emit = j >= m0 && j < m_end;
         const int e = emit ? j * HOP + lane : 0;
         UPX_GLOBAL float* out_l = opaque(a.out_l);
         UPX_GLOBAL float* out_r = opaque(a.out_r);
+        const int last = a.t_out - 1;
+        float old_l[HS], old_r[HS];
 #pragma unroll
         for (int s = 0; s < HS; ++s) {
-#if defined(UPX_EXP) && UPX_EXP >= 5
-            if (emit && e + s * LANES < a.t_out && th.acc_l[s] != th.acc_l[s]) {
-#else
-            if (emit && e + s * LANES < a.t_out) {
-#endif
-                UPX_GLOBAL float* pl = opaque(out_l + s * LANES) + e;
-                UPX_GLOBAL float* pr = opaque(out_r + s * LANES) + e;
-                if (a.accumulate) {
-                    *pl += th.acc_l[s];
-                    *pr += th.acc_r[s];
-                } else {
-                    *pl = th.acc_l[s];
-                    *pr = th.acc_r[s];
-                }
+            const int n = e + s * LANES;
+            const int nc = n < last ? n : last;
+            old_l[s] = a.accumulate ? out_l[nc] : 0.f;
+            old_r[s] = a.accumulate ? out_r[nc] : 0.f;
+        }
+        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
+        S::template pass_compute<LAST>(th, tw, lane);
+        const UPX_GLOBAL float* w_s = opaque(a.w_s);
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const float w = opaque(w_s + s * LANES)[lane];
+            th.acc_l[s] += th.x[s].y * w;   // swapped output: Re y = x.y, Im y = x.x
+            th.acc_r[s] += th.x[s].x * w;
+        }
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            const int n = e + s * LANES;
+            if (emit && n <= last) {
+                out_l[n] = old_l[s] + th.acc_l[s];
+                out_r[n] = old_r[s] + th.acc_r[s];
             }
         }
 #pragma unroll
@@ -478,56 +463,56 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     };
     auto tail_c = [&](int tid, Thread& th, int it) {
         const int lane = tid % LANES;
-        S::read_all(th, rd + (tid / LANES) * C::PITCH, lane);
-        S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
         const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
         const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
-        const UPX_GLOBAL float* w_s = opaque(a.w_s);
         UPX_GLOBAL float* out_c = opaque(a.out_c);
+        const int last = a.t_out - 1;
+        const int ja = m0 - (K - 1) + 2 * it;
+        float old_c[2][HS];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int j = m0 - (K - 1) + 2 * it + half;
-#pragma unroll
-            for (int s = 0; s < P; ++s) {
-#if defined(UPX_EXP) && UPX_EXP >= 3
-                const float w = 0.001f;
-#else
-                const float w = opaque(w_s + s * LANES)[lane];
-#endif
-                // swapped output: c_a = Re y = x.y ; c_b = Im y = x.x
-                th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w;
-            }
+            const int j = ja + half;
             const bool emit = j >= m0 && j < m_end;
             const int e = emit ? j * HOP + lane : 0;
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
-#if defined(UPX_EXP) && UPX_EXP >= 5
-                if (emit && e + s * LANES < a.t_out && th.acc_c[s] != th.acc_c[s]) {
-#else
-                if (emit && e + s * LANES < a.t_out) {
-#endif
-                    UPX_GLOBAL float* pc = opaque(out_c + s * LANES) + e;
-                    if (a.accumulate) *pc += th.acc_c[s];
-                    else *pc = th.acc_c[s];
-                }
+                const int n = e + s * LANES;
+                old_c[half][s] = a.accumulate ? out_c[n < last ? n : last] : 0.f;
+            }
+        }
+        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
+        S::template pass_compute<LAST>(th, tw, lane);
+        const UPX_GLOBAL float* w_s = opaque(a.w_s);
+        float w[P];
+#pragma unroll
+        for (int s = 0; s < P; ++s) w[s] = opaque(w_s + s * LANES)[lane];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int j = ja + half;
+#pragma unroll
+            for (int s = 0; s < P; ++s)   // swapped output: c_a = Re y = x.y ; c_b = Im y = x.x
+                th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w[s];
+            const bool emit = j >= m0 && j < m_end;
+            const int e = emit ? j * HOP + lane : 0;
+#pragma unroll
+            for (int s = 0; s < HS; ++s) {
+                const int n = e + s * LANES;
+                if (emit && n <= last) out_c[n] = old_c[half][s] + th.acc_c[s];
             }
 #pragma unroll
             for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
         }
     };
-    // passes 1..n-2, each: read what the previous phase wrote, transform, write the other buffer
-    auto mids = [&]() {
-        S::template mid_passes<1>(ex, rd, wr, a.tw);
-    };
-    // split L/R, gain, mask, build the iFFT input.  Partners Z[N-k] come from rd (natural
-    // index); the mirrored bins Y[N-k] go to wr at their natural index (N/2 = Nyquist, lane 0).
+    // split L/R, gain, mask, build the iFFT input.  Partners Z[N-k] are read from the upper
+    // region [N/2, N); the mirrored bins Y[N-k] go to the (free) lower region at position
+    // (N-k) - N/2, position 0 = Nyquist (lane 0).
     auto mask = [&](int tid, Thread& th, int half) {
         const int lane = tid % LANES;
+        cf* lds = lds_all + (tid / LANES) * C::PITCH;
         const UPX_GLOBAL float* gain = opaque(a.gain);
-        // k_s = lane + s LANES:  padp<P>(N - k_s) = padp<P>(N - lane - 7 LANES) + (7 - s) SP
-        const cf* zpart = rd + (tid / LANES) * C::PITCH + padp<P>(N - lane - (H - 1) * LANES);
-        cf* ymir = wr + (tid / LANES) * C::PITCH + padp<P>(N - lane - (H - 1) * LANES);
-        cf* ynyq = wr + (tid / LANES) * C::PITCH + padp<P>(N / 2);
+        // k_s = lane + s LANES:  padp(N - k_s) = padp(N - lane - (H-1) LANES) + (H-1-s) SP
+        const cf* zpart = lds + padp<P>(N - lane - (H - 1) * LANES);
+        cf* ymir = lds + padp<P>(N / 2 - lane - (H - 1) * LANES);
         cf nyq_y = mk(0.f, 0.f);
         float nyq_c = 0.f;
         if (lane == 0) {
@@ -542,11 +527,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
         for (int s = 0; s < H; ++s) {
             const bool dc = s == 0 && lane == 0;   // k == 0
-#if defined(UPX_EXP) && UPX_EXP >= 3
-            const float g2 = 0.5f;
-#else
             const float g2 = opaque(gain + s * LANES)[lane];
-#endif
             const cf za = th.x[s];
             const cf zp = zpart[(H - 1 - s) * SP];   // for k == 0 this is index N (spare row), unused
             const cf zb = dc ? za : zp;              // DC pairs with itself
@@ -561,7 +542,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             const cf ym = mk(ls.x + rs.y, rs.x - ls.y);
             th.x[s] = cswap(yk);
             if (s == 0) {
-                cf* dst = lane == 0 ? ynyq : ymir + (H - 1) * SP;   // lane 0: k == 0 has no mirror; it owns Nyquist
+                cf* dst = lane == 0 ? lds : ymir + (H - 1) * SP;   // lane 0: Nyquist at position 0
                 *dst = cswap(lane == 0 ? nyq_y : ym);
             } else {
                 ymir[(H - 1 - s) * SP] = cswap(ym);
@@ -584,36 +565,52 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             }
         }
     };
-    // first inverse pass: slots >= H hold Y[lane + s LANES] (natural index) written by the other lanes
+    // first inverse pass: slots >= H hold Y[lane + s LANES], parked at position idx - N/2
     auto inv0 = [&](int tid, Thread& th) {
         const int lane = tid % LANES;
-        const cf* b = rd + (tid / LANES) * C::PITCH + padp<P>(lane);
+        const cf* b = lds_all + (tid / LANES) * C::PITCH + padp<P>(lane);
 #pragma unroll
-        for (int s = H; s < P; ++s) th.x[s] = b[s * SP];
-        S::template pass_compute_write<0>(th, wr + (tid / LANES) * C::PITCH, opaque(a.tw), lane);
+        for (int s = H; s < P; ++s) th.x[s] = b[(s - H) * SP];
+        S::template pass_compute<0>(th, tw, lane);
     };
-    auto zsplit = [&](int tid, Thread& th) {
-        const int lane = tid % LANES;
-        S::read_all(th, rd + (tid / LANES) * C::PITCH, lane);
-        S::template pass_compute_final<LAST>(th, opaque(a.tw), lane);
-        cf* b = wr + (tid / LANES) * C::PITCH + padp<P>(lane);
+    auto scatter0 = [&](int tid, Thread& th) {
+        S::template pass_write<0>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES);
+    };
+    auto mids = [&]() { S::template mid_passes<1>(ex, lds_all, tw); };
+    auto zsplit_compute = [&](int tid, Thread& th) {
+        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES);
+        S::template pass_compute<LAST>(th, tw, tid % LANES);
+    };
+    auto zsplit_write = [&](int tid, Thread& th) {
+        cf* b = lds_all + (tid / LANES) * C::PITCH + padp<P>(tid % LANES);
 #pragma unroll
         for (int s = H; s < P; ++s) b[s * SP] = th.x[s];
     };
     auto stage_c = [&](int tid, Thread& th) {
         const int lane = tid % LANES;
-        cf* ymir = wr + (tid / LANES) * C::PITCH + padp<P>(N - lane - (H - 1) * LANES);
-        cf* ynyq = wr + (tid / LANES) * C::PITCH + padp<P>(N / 2);
+        cf* lds = lds_all + (tid / LANES) * C::PITCH;
+        cf* ymir = lds + padp<P>(N / 2 - lane - (H - 1) * LANES);
 #pragma unroll
         for (int s = 0; s < H; ++s) {
             th.x[s] = th.cs[s];
             if (s == 0) {
-                cf* dst = lane == 0 ? ynyq : ymir + (H - 1) * SP;
+                cf* dst = lane == 0 ? lds : ymir + (H - 1) * SP;
                 *dst = th.part[0];
             } else {
                 ymir[(H - 1 - s) * SP] = th.part[s];
             }
         }
+    };
+    // forward transform from the scattered pass 0 to the iFFT input, then the inverse passes
+    auto frame_body = [&](int half) {
+        ex.each(scatter0);
+        mids();
+        ex.each(zsplit_compute);
+        ex.each(zsplit_write);
+        ex.each([&](int tid, Thread& th) { mask(tid, th, half); });
+        ex.each(inv0);
+        ex.each(scatter0);
+        mids();
     };
 
     ex.each([&](int, Thread& th) {
@@ -622,61 +619,38 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     });
 
     for (int it = 0; it < n_iter; ++it) {
-        // ---- frame a ----------------------------------------------------------
         ex.each([&](int tid, Thread& th) {
             if (it > 0) tail_c(tid, th, it - 1);
             head(tid, th, it, 0);
         });
-        flip();
-        mids();
-        ex.each([&](int tid, Thread& th) { zsplit(tid, th); });
-        flip();
-        ex.each([&](int tid, Thread& th) { mask(tid, th, 0); });
-        flip();
-        ex.each([&](int tid, Thread& th) { inv0(tid, th); });
-        flip();
-        mids();
-        // ---- frame b ----------------------------------------------------------
+        frame_body(0);
         ex.each([&](int tid, Thread& th) {
             tail_lr(tid, th, it, 0);
             head(tid, th, it, 1);
         });
-        flip();
-        mids();
-        ex.each([&](int tid, Thread& th) { zsplit(tid, th); });
-        flip();
-        ex.each([&](int tid, Thread& th) { mask(tid, th, 1); });
-        flip();
-        ex.each([&](int tid, Thread& th) { inv0(tid, th); });
-        flip();
-        mids();
-        // ---- centre pair ------------------------------------------------------
-        ex.each([&](int tid, Thread& th) {
-            tail_lr(tid, th, it, 1);
-            stage_c(tid, th);
-        });
-        flip();
-        ex.each([&](int tid, Thread& th) { inv0(tid, th); });
-        flip();
+        frame_body(1);
+        ex.each([&](int tid, Thread& th) { tail_lr(tid, th, it, 1); });
+        ex.each(stage_c);
+        ex.each(inv0);
+        ex.each(scatter0);
         mids();
     }
     ex.each([&](int tid, Thread& th) { tail_c(tid, th, n_iter - 1); });
 }
 
-// Host-side helper: fill the twiddle table for Cfg (double precision -> float).
+// Host-side helper: fill the compact twiddle table for Cfg (double precision -> float).
+// Row (pass p, input r >= 1) holds W_(NS*R)^(r*k) for k = 0..NS-1 at tw_offset(p) + (r-1)*NS + k.
 template <class C, class TrigFn>
 inline void fill_twiddles(cf* tw, TrigFn trig) {
     using PS = typename C::PS;
     for (int p = 1; p < PS::n; ++p) {
-        const int R = PS::r[p], NS = pass_ns(PS::r, p), NB = C::P / R, row0 = tw_rows_before(PS::r, p, C::P);
-        for (int q = 0; q < NB; ++q)
-            for (int r = 1; r < R; ++r)
-                for (int lane = 0; lane < C::LANES; ++lane) {
-                    const int k = (lane + q * C::LANES) & (NS - 1);
-                    double c, s;
-                    trig((double)r * (double)k / ((double)NS * (double)R), c, s);   // fraction of a turn
-                    tw[(row0 + q * (R - 1) + (r - 1)) * C::LANES + lane] = mk((float)c, (float)-s);
-                }
+        const int R = PS::r[p], NS = pass_ns(PS::r, p), off = tw_offset(PS::r, p);
+        for (int r = 1; r < R; ++r)
+            for (int k = 0; k < NS; ++k) {
+                double c, s;
+                trig((double)r * (double)k / ((double)NS * (double)R), c, s);   // fraction of a turn
+                tw[off + (r - 1) * NS + k] = mk((float)c, (float)-s);
+            }
     }
 }
 

@@ -110,7 +110,7 @@ __global__ void upx_seam_add_kernel(float* c, float* l, float* r, const float* p
 struct KernelEntry {
     void (*launch)(const upx::BandArgs&, int n_wg, hipStream_t);
     int (*prepare)();
-    int wg, g, lds_bytes, tw_rows, lanes, wpe;
+    int wg, g, lds_bytes, tw_cf, lanes, wpe;
     void (*fill_tw)(upx::cf*);
     const char* name;
 };
@@ -133,7 +133,7 @@ struct Entry {
     }
     static void fill(upx::cf* tw) { upx::fill_twiddles<C>(tw, turn_trig); }
     static KernelEntry get(const char* name) {
-        return KernelEntry{&launch, &prepare, C::WG, C::G, kLds, C::TW_ROWS, C::LANES, WPE, &fill, name};
+        return KernelEntry{&launch, &prepare, C::WG, C::G, kLds, C::TW_CF, C::LANES, WPE, &fill, name};
     }
 };
 
@@ -328,7 +328,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         const int tw_key = s.log2n * 100000 + s.kern->lanes;   // layout depends on points per lane
         auto it = p->tw.find(tw_key);
         if (it == p->tw.end()) {
-            const size_t cnt = (size_t)(s.kern->tw_rows > 0 ? s.kern->tw_rows : 1) * s.kern->lanes;
+            const size_t cnt = (size_t)s.kern->tw_cf;
             std::vector<upx::cf> host(cnt);
             s.kern->fill_tw(host.data());
             upx::cf* d = nullptr;
