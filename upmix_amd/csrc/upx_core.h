@@ -282,6 +282,7 @@ struct ThreadT {
     float acc_c[P];
     cf cs[P / 2];     // centre spectrum of the pair: C_a, then Yc[k]
     cf part[P / 2];   // Yc[N-k] of the pair
+    cf pre[P];        // (first P/K used) raw samples of the NEXT frame's new hop, fetched one frame ahead
 };
 
 template <class C>
@@ -394,15 +395,39 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     });
 
     // ---- pieces (per thread) ------------------------------------------------
-    auto head = [&](int tid, Thread& th, int it, int half) {
-        const int lane = tid % LANES;
+    // Frame j of a stream covers samples j HOP + lane + s LANES.  Slots s < P-HS were part of the
+    // previous frame (L2 hits); the HS "new hop" slots are HBM misses, so they are fetched one frame
+    // ahead into th.pre and only consumed here.
+    auto frame_of = [&](int tid, int it, int half, bool& exists) {
         const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
         const int j = m0 - (K - 1) + 2 * it + half;
         const int j_first = m0 - (K - 1) > a.j_lo ? m0 - (K - 1) : a.j_lo;
         // one frame past the emitted range is still transformed: it is the pair partner of
         // frame m0+F-1 (for even F), and pairing must not depend on how streams are cut
         const int j_end = m0 + F + 1 < a.j_hi ? m0 + F + 1 : a.j_hi;
-        const bool exists = j >= j_first && j < j_end;
+        exists = j >= j_first && j < j_end;
+        return j;
+    };
+    auto prefetch = [&](int tid, Thread& th, int it, int half) {
+        bool exists;
+        const int j = frame_of(tid, it, half, exists);
+        const int e = exists ? j * HOP + tid % LANES : 0;
+        const UPX_GLOBAL cf* in = opaque(a.in);
+        const int last = a.t_in - 1;
+#pragma unroll
+        for (int s = P - HS; s < P; ++s) {
+            const int n = e + s * LANES;
+#if defined(UPX_EXP) && UPX_EXP >= 4
+            th.pre[s - (P - HS)] = mk(0.01f * (n & 7), 0.02f);
+#else
+            th.pre[s - (P - HS)] = in[n < last ? n : last];
+#endif
+        }
+    };
+    auto head = [&](int tid, Thread& th, int it, int half) {
+        const int lane = tid % LANES;
+        bool exists;
+        const int j = frame_of(tid, it, half, exists);
         const int e = exists ? j * HOP + lane : 0;
         const UPX_GLOBAL cf* in = opaque(a.in);
         const UPX_GLOBAL float* w_a = opaque(a.w_a);
@@ -412,11 +437,23 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             // always load an in-range sample, then zero what lies past the signal or in a
             // frame this stream does not own (zero-extension of center_extraction.py:437-455)
             const int n = e + s * LANES;
-            const cf v = in[n < last ? n : last];
+            cf v;
+#if defined(UPX_EXP) && UPX_EXP >= 4
+            if (s < P - HS) v = mk(0.01f * (n & 7), 0.02f);
+#else
+            if (s < P - HS) v = in[n < last ? n : last];
+#endif
+            else v = th.pre[s - (P - HS)];
+#if defined(UPX_EXP) && UPX_EXP >= 3
+            const float w = (exists && n <= last) ? 0.5f : 0.f;
+#else
             const float w = (exists && n <= last) ? opaque(w_a + s * LANES)[lane] : 0.f;
+#endif
             th.x[s] = mk(v.x * w, v.y * w);
         }
         S::template pass_compute<0>(th, tw, lane);
+        UPX_SCHED_FENCE();   // keep the prefetch behind the loads this frame waits for (vmcnt retires in order)
+        prefetch(tid, th, it + (half == 1 ? 1 : 0), half == 1 ? 0 : 1);
     };
     // read-modify-write of one emitted hop: the old values are fetched BEFORE the final pass
     // so that their HBM latency overlaps the butterflies
@@ -435,22 +472,34 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         for (int s = 0; s < HS; ++s) {
             const int n = e + s * LANES;
             const int nc = n < last ? n : last;
+#if defined(UPX_EXP) && UPX_EXP >= 5
+            old_l[s] = 0.f; old_r[s] = 0.f; (void)nc;
+#else
             old_l[s] = a.accumulate ? out_l[nc] : 0.f;
             old_r[s] = a.accumulate ? out_r[nc] : 0.f;
+#endif
         }
         S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
         S::template pass_compute<LAST>(th, tw, lane);
         const UPX_GLOBAL float* w_s = opaque(a.w_s);
 #pragma unroll
         for (int s = 0; s < P; ++s) {
+#if defined(UPX_EXP) && UPX_EXP >= 3
+            const float w = 0.001f;
+#else
             const float w = opaque(w_s + s * LANES)[lane];
+#endif
             th.acc_l[s] += th.x[s].y * w;   // swapped output: Re y = x.y, Im y = x.x
             th.acc_r[s] += th.x[s].x * w;
         }
 #pragma unroll
         for (int s = 0; s < HS; ++s) {
             const int n = e + s * LANES;
+#if defined(UPX_EXP) && UPX_EXP >= 5
+            if (emit && n <= last && th.acc_l[s] != th.acc_l[s]) {
+#else
             if (emit && n <= last) {
+#endif
                 out_l[n] = old_l[s] + th.acc_l[s];
                 out_r[n] = old_r[s] + th.acc_r[s];
             }
@@ -477,7 +526,11 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
                 const int n = e + s * LANES;
+#if defined(UPX_EXP) && UPX_EXP >= 5
+                old_c[half][s] = 0.f;
+#else
                 old_c[half][s] = a.accumulate ? out_c[n < last ? n : last] : 0.f;
+#endif
             }
         }
         S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
@@ -485,7 +538,11 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const UPX_GLOBAL float* w_s = opaque(a.w_s);
         float w[P];
 #pragma unroll
+#if defined(UPX_EXP) && UPX_EXP >= 3
+        for (int s = 0; s < P; ++s) w[s] = 0.001f;
+#else
         for (int s = 0; s < P; ++s) w[s] = opaque(w_s + s * LANES)[lane];
+#endif
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int j = ja + half;
@@ -497,7 +554,11 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
                 const int n = e + s * LANES;
+#if defined(UPX_EXP) && UPX_EXP >= 5
+                if (emit && n <= last && th.acc_c[s] != th.acc_c[s]) out_c[n] = old_c[half][s] + th.acc_c[s];
+#else
                 if (emit && n <= last) out_c[n] = old_c[half][s] + th.acc_c[s];
+#endif
             }
 #pragma unroll
             for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
@@ -527,7 +588,11 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
         for (int s = 0; s < H; ++s) {
             const bool dc = s == 0 && lane == 0;   // k == 0
+#if defined(UPX_EXP) && UPX_EXP >= 3
+            const float g2 = 0.5f;
+#else
             const float g2 = opaque(gain + s * LANES)[lane];
+#endif
             const cf za = th.x[s];
             const cf zp = zpart[(H - 1 - s) * SP];   // for k == 0 this is index N (spare row), unused
             const cf zb = dc ? za : zp;              // DC pairs with itself
@@ -613,9 +678,10 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         mids();
     };
 
-    ex.each([&](int, Thread& th) {
+    ex.each([&](int tid, Thread& th) {
 #pragma unroll
         for (int s = 0; s < P; ++s) th.acc_l[s] = th.acc_r[s] = th.acc_c[s] = 0.f;
+        prefetch(tid, th, 0, 0);
     });
 
     for (int it = 0; it < n_iter; ++it) {
