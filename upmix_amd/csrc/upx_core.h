@@ -684,11 +684,15 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         prefetch(tid, th, 0, 0);
     });
 
-    for (int it = 0; it < n_iter; ++it) {
+    // One extra trip runs only the centre tail of the last pair.  tail_c is instantiated ONCE
+    // (inside this loop) on purpose: two inlined copies may contract multiply-adds differently,
+    // and which copy a frame meets would then depend on how the signal is cut into streams.
+    for (int it = 0; it <= n_iter; ++it) {
         ex.each([&](int tid, Thread& th) {
             if (it > 0) tail_c(tid, th, it - 1);
-            head(tid, th, it, 0);
+            if (it < n_iter) head(tid, th, it, 0);
         });
+        if (it == n_iter) break;
         frame_body(0);
         ex.each([&](int tid, Thread& th) {
             tail_lr(tid, th, it, 0);
@@ -701,7 +705,6 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         ex.each(scatter0);
         mids();
     }
-    ex.each([&](int tid, Thread& th) { tail_c(tid, th, n_iter - 1); });
 }
 
 // Host-side helper: fill the compact twiddle table for Cfg (double precision -> float).
