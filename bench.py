@@ -113,7 +113,15 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     import upmix_amd as ux
-    from upmix_amd import sharding
+    from upmix_amd import sharding, _lib
+    n_dev = _lib.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    if local_rank >= n_dev:
+        # rehearsal of the N-rank path on a box with fewer GPUs (ranks share a device); not a valid bench line
+        print(f"[bench] WARNING: LOCAL_RANK {local_rank} >= {n_dev} visible device(s): sharing device {local_rank % n_dev}",
+              file=sys.stderr)
+    local_rank = local_rank % n_dev
 
     nominal = int(SR * args.seconds)
     bands = ux.chain_bands(EDGES, 0.75, ux.make_blackman_harris, SR, max_block_size=MAX_STFT, verbose=False,

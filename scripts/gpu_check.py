@@ -66,9 +66,39 @@ def c3_timing(seconds=600, reps=5):
         print(f"C3 prefix {name}: rms err {rms(g[:pre-8192].astype(np.float64) - r[:pre-8192]):.2e}")
 
 
+def default_plan_timing(seconds=600, reps=3):
+    """The reference's own default plan (STFT up to 65536) at C3 length."""
+    sr = 48000
+    total = sr * seconds
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, sr, verbose=False)
+    plan = ux.DevicePlan(bands)
+    x = orc.synthetic_stereo(total, 2)
+    d_in = plan.alloc(total * 8)
+    d_out = [plan.alloc(total * 4) for _ in range(3)]
+    plan.h2d(d_in, x)
+    plan.enable_timing(True)
+    for r in range(reps):
+        t0 = time.perf_counter()
+        plan.process_device(d_in, total, total, d_out[0], d_out[1], d_out[2], total)
+        plan.sync()
+        dt = time.perf_counter() - t0
+        print(f"default plan rep {r}: wall {dt*1e3:.2f} ms bands {np.round(plan.band_times_ms(), 3).tolist()} "
+              f"sizes {[b.block_size for b in bands]}", flush=True)
+    pre = sr * 4
+    outs = [np.empty(pre, np.float32) for _ in range(3)]
+    for o, d in zip(outs, d_out):
+        plan.d2h(o, d)
+    ob = orc.plan_bands([0, 30, 120, 480, 1920, 7680], 0.75, orc.win_blackman_harris, sr)
+    ref = orc.extract_multi_band(x[:pre + 65536, 0].astype(np.float64), x[:pre + 65536, 1].astype(np.float64), ob)
+    for name, g, r in zip("C L R".split(), outs, ref):
+        print(f"default plan prefix {name}: rms err {rms(g[:pre-65536].astype(np.float64) - r[:pre-65536]):.2e}")
+
+
 if __name__ == "__main__":
     print("variant", os.environ.get("UPX_KERNEL_VARIANT", "0"))
     if "parity" in sys.argv:
         parity()
     if "c3" in sys.argv:
         c3_timing()
+    if "default" in sys.argv:
+        default_plan_timing()

@@ -140,3 +140,31 @@ def test_silence_is_exact_zero(emu):
     band = orc.Band(256, 0.75, 7680., 24000., 48000, "raised_cosine", 480., 6000.)
     got = run_emu(emu, band, np.zeros((3000, 2), np.float32), 5)
     assert all(not g.any() for g in got)
+
+
+def test_large_stft_four_step_path(emu):
+    """STFT 16384..65536 (upx_big.h): chunked four-step transform, vs the oracle."""
+    if PTS[0] != 16:
+        pytest.skip("the four-step path has one build")
+    emu.emu_big_band.argtypes = [ctypes.c_int, ctypes.c_int, fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong,
+                                 fp, fp, fp] + [ctypes.c_int] * 6
+    for n, total, ch, lo, hi, wl, wh, ov in ((16384, 70000, 8, 120., 480., 30., 120., 0.75),
+                                             (65536, 150000, 6, 0., 30., 0., 7.5, 0.75),
+                                             (32768, 100000, 8, 30., 120., 7.5, 30., 0.75),
+                                             (16384, 50000, 6, 120., 480., 30., 120., 0.5)):
+        band = orc.Band(n, ov, lo, hi, 48000, "raised_cosine", wl, wh)
+        k = n // band.hop_size
+        x = orc.synthetic_stereo(total, n)
+        ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+        frames = -(-total // band.hop_size)
+        w_a = np.ascontiguousarray(band.analysis_window)
+        w_s = (band.synthesis_window / np.float32(n)).astype(np.float32)
+        gain = (0.5 * orc.band_gain(band)).astype(np.float32)
+        outs = [np.full(total, np.nan, np.float32) for _ in range(3)]
+        xin = np.ascontiguousarray(x)
+        rc = emu.emu_big_band(int(np.log2(n)), k, P(xin), total, P(outs[0]), P(outs[1]), P(outs[2]), total, P(w_a),
+                              P(w_s), P(gain), 0, frames, 0, frames, ch, 0)
+        assert rc == 0
+        for g, r in zip(outs, ref):
+            assert not np.isnan(g).any()
+            assert rms(g.astype(np.float64) - r) < 1e-7, n

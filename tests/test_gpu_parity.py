@@ -88,11 +88,10 @@ def test_unsupported_shapes_fail_loudly(ux):
     bex = ux.MultiBandExtractorAccu(512, 0.6, ux.make_hamming, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
     with pytest.raises(NotImplementedError):
         bex.process_all_blocks(x[:, 0], x[:, 1])
-    # the reference's default plan (STFT 65536) is a later row of SURVEY 8(f)
-    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 48000, verbose=False)
-    assert bands[0].block_size == 65536
+    # sizes outside 256..65536 are not covered
+    bex = ux.MultiBandExtractorAccu(128, 0.75, ux.make_hann, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
     with pytest.raises(NotImplementedError):
-        ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, bands)
+        bex.process_all_blocks(x[:, 0], x[:, 1])
     with pytest.raises(ValueError):
         ux.MultiBandExtractorAccu(4, 0.9, ux.make_hann, 0.0, 100.0, 48000)
 
@@ -109,6 +108,25 @@ def test_golden_multi_band(ux):
         out = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], bands[0].sr, bands)
         for got, k in zip(out, "clr"):
             close(got, z[f"{name}_{k}"])
+
+
+def test_reference_default_plan_stft_65536(ux, orc):
+    """chain_bands with the reference's own defaults -> [65536, 65536, 16384, 4096, 1024, 256]."""
+    z = load_golden("f5_multiband.npz")
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 48000, verbose=False)
+    assert [b.block_size for b in bands] == [65536, 65536, 16384, 4096, 1024, 256]
+    x = z["default_65536_x"]
+    out = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, bands)
+    for got, k in zip(out, "clr"):
+        close(got, z[f"default_65536_{k}"])
+    # longer signal (several chunks per band), 96 kHz plan [65536 x2, 32768, 8192, 2048, 512], vs the oracle
+    x = orc.synthetic_stereo(1_500_000, 12)
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 96000, verbose=False)
+    ob = orc.plan_bands([0, 30, 120, 480, 1920, 7680], 0.75, orc.win_blackman_harris, 96000)
+    assert [b.block_size for b in bands] == [65536, 65536, 32768, 8192, 2048, 512]
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+    for got, r in zip(ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 96000, bands), ref):
+        close(got, r)
 
 
 def test_golden_degenerate_inputs(ux):

@@ -136,7 +136,8 @@ def test_c_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.upx_abi_version() == 1
-    assert lib.upx_supported(8192, 2048) == 1 and lib.upx_supported(65536, 16384) == 0
+    assert lib.upx_supported(8192, 2048) == 1 and lib.upx_supported(65536, 16384) == 1
+    assert lib.upx_supported(131072, 32768) == 0 and lib.upx_supported(128, 32) == 0
     assert lib.upx_supported(512, 204) == 0
 
 

@@ -17,6 +17,7 @@
 
 #include "../../include/upmix_hip.h"
 #include "upx_core.h"
+#include "upx_big.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -107,6 +108,38 @@ __global__ void upx_seam_add_kernel(float* c, float* l, float* r, const float* p
     }
 }
 
+// ---- STFT sizes 16384..65536: four-step transform through scratch (upx_big.h) ----------------
+template <class B>
+__global__ __launch_bounds__(256) void upx_big_step1_audio_kernel(upx::BigArgs a) {
+    upx::big_step1_audio<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+template <class B>
+__global__ __launch_bounds__(256) void upx_big_step1_spec_kernel(upx::cf* buf, const upx::cf* tw_n, int frames) {
+    upx::big_step1_spec<B>(buf, tw_n, frames, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+template <class B>
+__global__ __launch_bounds__(B::Row::WG) void upx_big_rows_kernel(upx::cf* buf, const upx::cf* tw_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<B::Row::WAVE_SYNC, B::Row::P> ex;
+    upx::big_rows_program<B>(ex, buf, tw_rows, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+}
+template <class B>
+__global__ __launch_bounds__(256) void upx_big_mask_kernel(upx::BigArgs a) {
+    upx::big_mask<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+template <class B, int K>
+__global__ __launch_bounds__(256) void upx_big_ola_kernel(upx::BigArgs a) {
+    upx::big_ola<B, K>(a, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+struct BigEntry {
+    int n, n2, k, row_wg, row_lds, row_tw_cf;
+    void (*chunk)(const upx::BigArgs&, hipStream_t);
+    int (*prepare)();
+    void (*fill_tw_n)(upx::cf*);
+    void (*fill_tw_rows)(upx::cf*);
+};
+
 struct KernelEntry {
     void (*launch)(const upx::BandArgs&, int n_wg, hipStream_t);
     int (*prepare)();
@@ -119,6 +152,46 @@ void turn_trig(double frac, double& c, double& s) {
     const double a = 2.0 * M_PI * frac;
     c = std::cos(a);
     s = std::sin(a);
+}
+
+template <class B, int K>
+struct BigImpl {
+    using Row = typename B::Row;
+    static constexpr int kRowLds = Row::LDS_CF * (int)sizeof(upx::cf);
+    static unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
+    // all launches of one chunk, in stream order
+    static void chunk(const upx::BigArgs& a, hipStream_t st) {
+        const int ch = a.ch;
+        hipLaunchKernelGGL(upx_big_step1_audio_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3(ch * 16), dim3(Row::WG), kRowLds, st, a.z, a.tw_rows);
+        hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks((long long)(ch / 2) * (B::N / 2 + 1))), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(upx_big_step1_spec_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a.y, a.tw_n, ch);
+        hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3(ch * 16), dim3(Row::WG), kRowLds, st, a.y, a.tw_rows);
+        hipLaunchKernelGGL(upx_big_step1_spec_kernel<B>, dim3(blocks((long long)(ch / 2) * B::N2)), dim3(256), 0, st, a.yc, a.tw_n, ch / 2);
+        hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3((ch / 2) * 16), dim3(Row::WG), kRowLds, st, a.yc, a.tw_rows);
+        hipLaunchKernelGGL((upx_big_ola_kernel<B, K>), dim3(blocks((long long)(a.m1 - a.m0) * B::HOP)), dim3(256), 0, st, a);
+    }
+    static int prepare() {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_rows_kernel<B>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kRowLds);
+    }
+    static void fill_n(upx::cf* tw) { upx::fill_big_twiddles<B>(tw, turn_trig); }
+    static void fill_rows(upx::cf* tw) { upx::fill_twiddles<Row>(tw, turn_trig); }
+    static BigEntry get() { return BigEntry{B::N, B::N2, K, Row::WG, kRowLds, Row::TW_CF, &chunk, &prepare, &fill_n, &fill_rows}; }
+};
+
+const BigEntry* find_big(int log2n, int k) {
+    static const std::map<std::pair<int, int>, BigEntry> table = [] {
+        std::map<std::pair<int, int>, BigEntry> t;
+#define UPX_BIG(L, K) t[{L, K}] = BigImpl<upx::BigCfg<L, K>, K>::get();
+        UPX_BIG(14, 2) UPX_BIG(14, 4) UPX_BIG(14, 8)
+        UPX_BIG(15, 2) UPX_BIG(15, 4) UPX_BIG(15, 8)
+        UPX_BIG(16, 2) UPX_BIG(16, 4) UPX_BIG(16, 8)
+#undef UPX_BIG
+        return t;
+    }();
+    auto it = table.find({log2n, k});
+    return it == table.end() ? nullptr : &it->second;
 }
 
 template <class C, int WPE>
@@ -174,6 +247,9 @@ int ilog2_exact(int v) {
 struct BandState {
     int n = 0, hop = 0, k = 0, log2n = 0;
     const KernelEntry* kern = nullptr;
+    const BigEntry* big = nullptr;      // STFT > 8192: four-step path
+    upx::cf* d_tw_n = nullptr;          // W_N^(k1 n2) for the big path
+    int chunk_frames = 0;
     float* d_wa = nullptr;
     float* d_ws = nullptr;     // synthesis window / N
     float* d_gain = nullptr;   // 0.5 * gain
@@ -193,6 +269,8 @@ struct upx_plan {
     bool timing = false;
     bool timed_once = false;
     unsigned int* d_scalar = nullptr;
+    upx::cf* d_scratch = nullptr;   // z | y | yc of the big path (shared by all big bands)
+    size_t scratch_cf = 0;
 };
 
 struct upx_comm {
@@ -276,7 +354,7 @@ int upx_supported(int32_t block_size, int32_t hop) {
     if (block_size < 1 || hop < 1 || block_size % hop) return 0;
     const int l = ilog2_exact(block_size);
     if (l < 0) return 0;
-    return find_kernel(l, block_size / hop, 0) ? 1 : 0;
+    return (find_kernel(l, block_size / hop, 0) || find_big(l, block_size / hop)) ? 1 : 0;
 }
 
 int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* block_size, const int32_t* hop,
@@ -288,7 +366,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         if (!upx_supported(block_size[b], hop[b]))
             return fail(UPX_ERR_UNSUPPORTED,
                         "band %d: STFT size %d with hop %d is not covered by the gfx950 kernels "
-                        "(power-of-two sizes 256..8192, hop = N/2, N/4 or N/8)",
+                        "(power-of-two sizes 256..65536, hop = N/2, N/4 or N/8)",
                         b, block_size[b], hop[b]);
     }
     int n_dev = 0;
@@ -311,9 +389,10 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         s.k = s.n / s.hop;
         s.log2n = ilog2_exact(s.n);
         s.kern = find_kernel(s.log2n, s.k, default_variant());
-        if (int e = s.kern->prepare()) {
+        if (!s.kern) s.big = find_big(s.log2n, s.k);
+        if (int e = s.kern ? s.kern->prepare() : s.big->prepare()) {
             upx_plan_destroy(p);
-            return fail(UPX_ERR_HIP, "hipFuncSetAttribute(%s): %s", s.kern->name, hipGetErrorString((hipError_t)e));
+            return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
         }
         const int nb = s.n / 2 + 1;
         std::vector<float> ws(s.n), gh(nb);
@@ -325,23 +404,35 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         HIP_TRY(hipMemcpy(s.d_wa, w_analysis + off_w, s.n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.d_ws, ws.data(), s.n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.d_gain, gh.data(), nb * sizeof(float), hipMemcpyHostToDevice));
-        const int tw_key = s.log2n * 100000 + s.kern->lanes;   // layout depends on points per lane
+        const int tw_key = s.log2n * 100000 + (s.kern ? s.kern->lanes : 0);   // layout depends on points per lane
         auto it = p->tw.find(tw_key);
         if (it == p->tw.end()) {
-            const size_t cnt = (size_t)s.kern->tw_cf;
+            const size_t cnt = (size_t)(s.kern ? s.kern->tw_cf : s.big->row_tw_cf);
             std::vector<upx::cf> host(cnt);
-            s.kern->fill_tw(host.data());
+            if (s.kern) s.kern->fill_tw(host.data());
+            else s.big->fill_tw_rows(host.data());
             upx::cf* d = nullptr;
             HIP_TRY(hipMalloc(&d, cnt * sizeof(upx::cf)));
             HIP_TRY(hipMemcpy(d, host.data(), cnt * sizeof(upx::cf), hipMemcpyHostToDevice));
             it = p->tw.emplace(tw_key, d).first;
         }
         s.d_tw = it->second;
+        if (s.big) {
+            // chunks of ~4M complex per scratch buffer (32 MB: stays in L2 / Infinity Cache)
+            s.chunk_frames = (1 << 22) / s.n;
+            std::vector<upx::cf> host((size_t)s.n);
+            s.big->fill_tw_n(host.data());
+            HIP_TRY(hipMalloc(&s.d_tw_n, (size_t)s.n * sizeof(upx::cf)));
+            HIP_TRY(hipMemcpy(s.d_tw_n, host.data(), (size_t)s.n * sizeof(upx::cf), hipMemcpyHostToDevice));
+            const size_t need = (size_t)s.chunk_frames * s.n * 5 / 2;   // z + y + yc/2
+            if (need > p->scratch_cf) p->scratch_cf = need;
+        }
         HIP_TRY(hipEventCreate(&s.ev0));
         HIP_TRY(hipEventCreate(&s.ev1));
         off_w += s.n;
         off_g += nb;
     }
+    if (p->scratch_cf) HIP_TRY(hipMalloc(&p->d_scratch, p->scratch_cf * sizeof(upx::cf)));
     *out = p;
     return UPX_OK;
 }
@@ -353,11 +444,13 @@ void upx_plan_destroy(upx_plan* p) {
         if (s.d_wa) (void)hipFree(s.d_wa);
         if (s.d_ws) (void)hipFree(s.d_ws);
         if (s.d_gain) (void)hipFree(s.d_gain);
+        if (s.d_tw_n) (void)hipFree(s.d_tw_n);
         if (s.ev0) (void)hipEventDestroy(s.ev0);
         if (s.ev1) (void)hipEventDestroy(s.ev1);
     }
     for (auto& kv : p->tw) (void)hipFree(kv.second);
     if (p->d_scalar) (void)hipFree(p->d_scalar);
+    if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -429,6 +522,37 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         if (b == 0) m_hi = m_all;                                   // first band initialises every output sample
         if (j_hi > 0x7fffffffLL || m_all > 0x7fffffffLL) return fail(UPX_ERR_INVALID, "signal too long for int32 frame index");
         if (m_hi <= 0) continue;
+        if (s.big) {
+            // chunked four-step path: each chunk transforms frames j0 .. j0+ch-1 (j0 odd) and emits
+            // the ch-K blocks whose K frames all lie inside it (the last frame is only a pair partner)
+            int ch = s.chunk_frames;
+            const long long want = m_hi + s.k;
+            if (want < ch) ch = (int)(want + (want & 1));
+            if (ch < s.k + 2) ch = s.k + 2;
+            upx::BigArgs a;
+            a.in = reinterpret_cast<const upx::cf*>(d_stereo);
+            a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
+            a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw_n = s.d_tw_n; a.tw_rows = s.d_tw;
+            a.z = p->d_scratch;
+            a.y = a.z + (size_t)ch * s.n;
+            a.yc = a.y + (size_t)ch * s.n;
+            a.t_in = (int)t_in; a.t_out = (int)t_out;
+            a.j_lo = 0; a.j_hi = (int)j_hi; a.ch = ch;
+            a.accumulate = b == 0 ? 0 : 1;
+            if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+            const int emit = ch - s.k;
+            int n_chunks = 0;
+            for (long long m0 = 0; m0 < m_hi; m0 += emit, ++n_chunks) {
+                a.j0 = (int)m0 - (s.k - 1);
+                a.m0 = (int)m0;
+                a.m1 = (int)(m0 + emit < m_hi ? m0 + emit : m_hi);
+                s.big->chunk(a, p->stream);
+            }
+            if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+            s.last_wg = n_chunks;
+            s.last_f = emit;
+            continue;
+        }
         // blocks per stream: fill every resident workgroup slot once, never fewer than 8 blocks
         int resident = (s.kern->wpe * 256) / s.kern->wg;              // workgroups per CU by registers
         const int by_lds = (160 * 1024) / s.kern->lds_bytes;              // ... and by LDS
@@ -516,8 +640,8 @@ int upx_plan_band_info(upx_plan* p, int band, int32_t* workgroups, int32_t* thre
     if (!p || band < 0 || band >= (int)p->bands.size()) return fail(UPX_ERR_INVALID, "upx_plan_band_info: bad argument");
     const BandState& s = p->bands[band];
     if (workgroups) *workgroups = s.last_wg;
-    if (threads) *threads = s.kern->wg;
-    if (lds_bytes) *lds_bytes = s.kern->lds_bytes;
+    if (threads) *threads = s.kern ? s.kern->wg : s.big->row_wg;
+    if (lds_bytes) *lds_bytes = s.kern ? s.kern->lds_bytes : s.big->row_lds;
     if (blocks_per_stream) *blocks_per_stream = s.last_f;
     return UPX_OK;
 }
