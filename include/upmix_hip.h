@@ -108,6 +108,14 @@ int upx_plan_band_times_ms(upx_plan* plan, float* ms, int n_bands);
 int upx_plan_band_info(upx_plan* plan, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,
                        int32_t* blocks_per_stream);
 
+/*
+ * Adjacent bands with the same STFT size, hop and windows are merged into ONE kernel launch (their
+ * transforms are identical linear operators; only the per-bin gain -> mask step is per band).
+ * Reports the first band of `band`'s group and the number of bands in it.  Timing and launch geometry
+ * of a group are reported on its first band.  Set UPX_NO_BAND_MERGE=1 to launch every band separately.
+ */
+int upx_plan_band_group(upx_plan* plan, int band, int32_t* leader, int32_t* size);
+
 /* max|x| over n floats on the device (peak normalisation of main.py:85-88). */
 int upx_absmax(upx_plan* plan, const float* d_x, int64_t n, float* result);
 /* x *= scale on the device (main.py:95-97). */

@@ -51,7 +51,7 @@ int run(upx::BandArgs a) {
 extern "C" int emu_band(int log2n, int k_overlap, int pts, const float* in, long long t_in, float* out_c, float* out_l,
                         float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
                         const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int blocks_per_stream,
-                        int accumulate) {
+                        int accumulate, int n_gain) {
     upx::BandArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = reinterpret_cast<const upx::cf*>(in);
@@ -60,6 +60,7 @@ extern "C" int emu_band(int log2n, int k_overlap, int pts, const float* in, long
     a.t_in = (int)t_in; a.t_out = (int)t_out;
     a.j_lo = j_lo; a.j_hi = j_hi; a.m_lo = m_lo; a.m_hi = m_hi;
     a.blocks_per_stream = blocks_per_stream; a.accumulate = accumulate;
+    a.n_gain = n_gain; a.gain_stride = (1 << log2n) / 2 + 1;
 #define UPX_CASE(L, K, PP) if (log2n == L && k_overlap == K && pts == PP) return run<upx::Cfg<L, K, PP>>(a);
     UPX_CASE(8, 4, 16) UPX_CASE(9, 4, 16) UPX_CASE(10, 4, 16) UPX_CASE(11, 4, 16) UPX_CASE(12, 4, 16) UPX_CASE(13, 4, 16)
     UPX_CASE(8, 2, 16) UPX_CASE(10, 2, 16) UPX_CASE(10, 8, 16) UPX_CASE(12, 8, 16) UPX_CASE(13, 2, 16)
@@ -112,7 +113,7 @@ int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch) {
 extern "C" int emu_big_band(int log2n, int k_overlap, const float* in, long long t_in, float* out_c, float* out_l,
                             float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
                             const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int chunk_frames,
-                            int accumulate) {
+                            int accumulate, int n_gain) {
     upx::BigArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = reinterpret_cast<const upx::cf*>(in);
@@ -120,6 +121,7 @@ extern "C" int emu_big_band(int log2n, int k_overlap, const float* in, long long
     a.w_a = w_a; a.w_s = w_s_scaled; a.gain = gain_half;
     a.t_in = (int)t_in; a.t_out = (int)t_out;
     a.j_lo = j_lo; a.j_hi = j_hi; a.accumulate = accumulate;
+    a.n_gain = n_gain; a.gain_stride = (1 << log2n) / 2 + 1;
 #define UPX_BIG(L, K) if (log2n == L && k_overlap == K) return run_big<upx::BigCfg<L, K>, K>(a, m_lo, m_hi, chunk_frames);
     UPX_BIG(14, 4) UPX_BIG(15, 4) UPX_BIG(16, 4) UPX_BIG(14, 2) UPX_BIG(14, 8)
 #undef UPX_BIG

@@ -30,7 +30,7 @@ def emu():
     path = ge.build_emulator()
     lib = ctypes.CDLL(path)
     lib.emu_band.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong,
-                             fp, fp, fp] + [ctypes.c_int] * 6
+                             fp, fp, fp] + [ctypes.c_int] * 7
     lib.emu_band.restype = ctypes.c_int
     return lib
 
@@ -39,7 +39,8 @@ def P(a):
     return a.ctypes.data_as(fp)
 
 
-def run_emu(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=None, t_out=None, pts=None):
+def run_emu(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=None, t_out=None, pts=None,
+            gain_table=None):
     pts = pts or PTS[0]
     n, hop = band.block_size, band.hop_size
     k = n // hop
@@ -50,12 +51,14 @@ def run_emu(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=No
     m_hi = min(j_hi + k - 1, -(-t_out // hop)) if accumulate else -(-t_out // hop)
     w_a = np.ascontiguousarray(band.analysis_window)
     w_s = (band.synthesis_window / np.float32(n)).astype(np.float32)
-    gain = (0.5 * orc.band_gain(band)).astype(np.float32)
+    gain = (0.5 * orc.band_gain(band)).astype(np.float32) if gain_table is None else gain_table
+    n_gain = 1 if gain_table is None else gain_table.shape[0]
+    gain = np.ascontiguousarray(gain)
     if outs is None:
         outs = [np.full(t_out, np.nan, np.float32) for _ in range(3)]
     xin = np.ascontiguousarray(x, dtype=np.float32)
     rc = lib.emu_band(int(np.log2(n)), k, pts, P(xin), t_in, P(outs[0]), P(outs[1]), P(outs[2]), t_out, P(w_a), P(w_s),
-                      P(gain), 0, j_hi, 0, m_hi, blocks_per_stream, accumulate)
+                      P(gain), 0, j_hi, 0, m_hi, blocks_per_stream, accumulate, n_gain)
     assert rc == 0
     return outs
 
@@ -147,7 +150,7 @@ def test_large_stft_four_step_path(emu):
     if PTS[0] != 16:
         pytest.skip("the four-step path has one build")
     emu.emu_big_band.argtypes = [ctypes.c_int, ctypes.c_int, fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong,
-                                 fp, fp, fp] + [ctypes.c_int] * 6
+                                 fp, fp, fp] + [ctypes.c_int] * 7
     for n, total, ch, lo, hi, wl, wh, ov in ((16384, 70000, 8, 120., 480., 30., 120., 0.75),
                                              (65536, 150000, 6, 0., 30., 0., 7.5, 0.75),
                                              (32768, 100000, 8, 30., 120., 7.5, 30., 0.75),
@@ -163,8 +166,32 @@ def test_large_stft_four_step_path(emu):
         outs = [np.full(total, np.nan, np.float32) for _ in range(3)]
         xin = np.ascontiguousarray(x)
         rc = emu.emu_big_band(int(np.log2(n)), k, P(xin), total, P(outs[0]), P(outs[1]), P(outs[2]), total, P(w_a),
-                              P(w_s), P(gain), 0, frames, 0, frames, ch, 0)
+                              P(w_s), P(gain), 0, frames, 0, frames, ch, 0, 1)
         assert rc == 0
         for g, r in zip(outs, ref):
             assert not np.isnan(g).any()
             assert rms(g.astype(np.float64) - r) < 1e-7, n
+
+
+def merged_gain_table(bands):
+    """gain[q][k]: the non-zero half-gains of bin k in band order, zero padded (what the library builds)."""
+    g = np.stack([0.5 * orc.band_gain(b) for b in bands]).astype(np.float32)
+    slots = int(max(1, (g != 0).sum(axis=0).max()))
+    table = np.zeros((slots, g.shape[1]), np.float32)
+    for k in range(g.shape[1]):
+        nz = g[:, k][g[:, k] != 0]
+        table[:len(nz), k] = nz
+    return table
+
+
+def test_merged_bands_equal_band_sum(emu):
+    """Bands sharing N/hop/windows run as ONE launch with a per-bin gain list; equals the sum of the separate bands."""
+    bands = orc.plan_bands([0, 30, 120, 480, 1920, 7680], 0.75, orc.win_blackman_harris, 48000, max_block_size=1024)[:4]
+    assert [b.block_size for b in bands] == [1024] * 4
+    x = orc.synthetic_stereo(9000, 8)
+    table = merged_gain_table(bands)
+    assert table.shape[0] == 2            # neighbouring raised-cosine bands overlap pairwise
+    got = run_emu(emu, bands[0], x, 6, gain_table=table)
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), bands)
+    for g, r in zip(got, ref):
+        assert rms(g.astype(np.float64) - r) < 1e-7

@@ -24,7 +24,8 @@ struct BigArgs {
     float* out_r;
     const float* w_a;      // analysis window [N]
     const float* w_s;      // synthesis window / N [N]
-    const float* gain;     // 0.5 * band-limit gain [N/2+1]
+    const float* gain;     // 0.5 * band-limit gain, [n_gain][gain_stride] (merged bands, see BandArgs)
+    int n_gain, gain_stride;
     const cf* tw_n;        // W_N^(k1 n2), [16][N2]
     const cf* tw_rows;     // compact twiddle table of the N2-point row transform
     cf* z;                 // scratch [CH][N]: forward spectra (bin k at (k&15) N2 + (k>>4))
@@ -122,18 +123,21 @@ UPX_HD void big_mask(const BigArgs& a, long long gid) {
     if (pp >= a.ch / 2) return;
     const int km = (N - k) & (N - 1);           // partner bin; k = 0 and k = N/2 pair with themselves
     const bool self = km == k;
-    const float g2 = a.gain[k];
     cf c2[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const size_t f = (size_t)(2 * pp + half) * N;
         const cf za = a.z[f + B::scr(k)];
         const cf zb = self ? za : a.z[f + B::scr(km)];
+        const cf l0 = mk(za.x + zb.x, za.y - zb.y), r0 = mk(za.y + zb.y, zb.x - za.x);
         cf c = mk(0.f, 0.f), ls = c, rs = c;
-        if (g2 != 0.f) {
-            cf l = mk(g2 * (za.x + zb.x), g2 * (za.y - zb.y));
-            cf r = mk(g2 * (za.y + zb.y), g2 * (zb.x - za.x));
-            mask_bin(l, r, c, ls, rs);
+        for (int q = 0; q < a.n_gain; ++q) {
+            const float g2 = a.gain[q * a.gain_stride + k];
+            if (g2 != 0.f) {
+                cf l = mk(g2 * l0.x, g2 * l0.y), r = mk(g2 * r0.x, g2 * r0.y), cq, lq, rq;
+                mask_bin(l, r, cq, lq, rq);
+                c = c + cq; ls = ls + lq; rs = rs + rq;
+            }
         }
         const cf yk = mk(ls.x - rs.y, ls.y + rs.x);
         const cf ym = mk(ls.x + rs.y, rs.x - ls.y);

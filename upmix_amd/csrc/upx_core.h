@@ -247,13 +247,19 @@ struct BandArgs {
     float* out_r;
     const float* w_a;      // analysis window [N]
     const float* w_s;      // synthesis window / N [N]
-    const float* gain;     // 0.5 * band-limit gain [N/2+1]
+    const float* gain;     // 0.5 * band-limit gain, [n_gain][gain_stride] (see below)
     const cf* tw;          // inter-pass twiddles, [row][LANES]
     int t_in;              // valid input samples  [0, t_in)
     int t_out;             // valid output samples [0, t_out)
     int j_lo, j_hi;        // frames that exist: j in [j_lo, j_hi), frame j starts at j*hop
     int m_lo, m_hi;        // hop-blocks to emit: m in [m_lo, m_hi)
     int blocks_per_stream; // F
+    // Adjacent bands that share N, hop and windows are MERGED into one launch: their transforms are
+    // the same linear operators, so sum_b OLA(iFFT(Y_b)) = OLA(iFFT(sum_b Y_b)) and only the per-bin
+    // gain -> mask step runs per band.  gain[q][k], q < n_gain, lists the non-zero band gains of bin k
+    // in band order (zero padded); n_gain = 1 for an unmerged band.
+    int n_gain;
+    int gain_stride;
     int accumulate;        // 0: out = band, 1: out += band (band sum in list order)
 };
 
@@ -576,31 +582,43 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         cf* ymir = lds + padp<P>(N / 2 - lane - (H - 1) * LANES);
         cf nyq_y = mk(0.f, 0.f);
         float nyq_c = 0.f;
+        const int n_gain = a.n_gain, gstride = a.gain_stride;
         if (lane == 0) {
             // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
-            const float g2 = gain[N / 2];
             const cf z = th.x[H];
-            cf l = mk(g2 * (z.x + z.x), 0.f), r = mk(g2 * (z.y + z.y), 0.f), c, ls, rs;
-            mask_bin(l, r, c, ls, rs);
-            nyq_y = mk(ls.x, rs.x);
-            nyq_c = c.x;
+            cf cn = mk(0.f, 0.f), lsn = cn, rsn = cn;
+            for (int q = 0; q < n_gain; ++q) {
+                const float g2 = gain[q * gstride + N / 2];
+                if (g2 != 0.f) {
+                    cf l = mk(g2 * (z.x + z.x), 0.f), r = mk(g2 * (z.y + z.y), 0.f), c, ls, rs;
+                    mask_bin(l, r, c, ls, rs);
+                    cn = cn + c; lsn = lsn + ls; rsn = rsn + rs;
+                }
+            }
+            nyq_y = mk(lsn.x, rsn.x);
+            nyq_c = cn.x;
         }
 #pragma unroll
         for (int s = 0; s < H; ++s) {
             const bool dc = s == 0 && lane == 0;   // k == 0
-#if defined(UPX_EXP) && UPX_EXP >= 3
-            const float g2 = 0.5f;
-#else
-            const float g2 = opaque(gain + s * LANES)[lane];
-#endif
             const cf za = th.x[s];
             const cf zp = zpart[(H - 1 - s) * SP];   // for k == 0 this is index N (spare row), unused
             const cf zb = dc ? za : zp;              // DC pairs with itself
+            const cf l0 = mk(za.x + zb.x, za.y - zb.y);   // Z[k] + conj Z[N-k]        (x gain/2 = L)
+            const cf r0 = mk(za.y + zb.y, zb.x - za.x);   // (Z[k] - conj Z[N-k]) / i  (x gain/2 = R)
             cf c = mk(0.f, 0.f), ls = c, rs = c;
-            if (g2 != 0.f) {
-                cf l = mk(g2 * (za.x + zb.x), g2 * (za.y - zb.y));   // g/2 (Z[k] + conj Z[N-k])
-                cf r = mk(g2 * (za.y + zb.y), g2 * (zb.x - za.x));   // g/2 (Z[k] - conj Z[N-k]) / i
-                mask_bin(l, r, c, ls, rs);
+            const UPX_GLOBAL float* gp = opaque(gain + s * LANES) + lane;
+            for (int q = 0; q < n_gain; ++q) {
+#if defined(UPX_EXP) && UPX_EXP >= 3
+                const float g2 = 0.5f;
+#else
+                const float g2 = gp[q * gstride];
+#endif
+                if (g2 != 0.f) {
+                    cf l = mk(g2 * l0.x, g2 * l0.y), r = mk(g2 * r0.x, g2 * r0.y), cq, lq, rq;
+                    mask_bin(l, r, cq, lq, rq);
+                    c = c + cq; ls = ls + lq; rs = rs + rq;
+                }
             }
             // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
             const cf yk = mk(ls.x - rs.y, ls.y + rs.x);

@@ -255,6 +255,9 @@ struct BandState {
     float* d_gain = nullptr;   // 0.5 * gain
     upx::cf* d_tw = nullptr;   // shared per N (owned by plan->tw)
     int blocks_override = 0;
+    int group_leader = 0;               // index of the band whose launch carries this band
+    int group_size = 1;                 // leader: bands merged into its launch; merged members: 0
+    int n_gain = 1;                     // gain slots per bin (merged bands overlap at crossovers)
     int last_wg = 0, last_f = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -382,6 +385,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     HIP_TRY(hipMalloc(&p->d_scalar, sizeof(unsigned int)));
     p->bands.resize(n_bands);
     size_t off_w = 0, off_g = 0;
+    std::vector<size_t> band_gain_off;
     for (int b = 0; b < n_bands; ++b) {
         BandState& s = p->bands[b];
         s.n = block_size[b];
@@ -395,15 +399,27 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
         }
         const int nb = s.n / 2 + 1;
-        std::vector<float> ws(s.n), gh(nb);
+        // Merge with the previous band when it has the same STFT size, hop and (bit-identical) windows:
+        // the transforms are then the same linear operators and only gain -> mask runs per band.
+        s.group_leader = b;
+        if (b > 0 && !std::getenv("UPX_NO_BAND_MERGE")) {
+            const BandState& q = p->bands[b - 1];
+            if (q.n == s.n && q.hop == s.hop &&
+                !std::memcmp(w_analysis + off_w, w_analysis + off_w - s.n, s.n * sizeof(float)) &&
+                !std::memcmp(w_synthesis + off_w, w_synthesis + off_w - s.n, s.n * sizeof(float)))
+                s.group_leader = q.group_leader;
+        }
+        if (s.group_leader != b) {
+            s.group_size = 0;
+            p->bands[s.group_leader].group_size += 1;
+        }
+        std::vector<float> ws(s.n);
         for (int i = 0; i < s.n; ++i) ws[i] = w_synthesis[off_w + i] / (float)s.n;   // exact: N is a power of two
-        for (int i = 0; i < nb; ++i) gh[i] = 0.5f * gain[off_g + i];
         HIP_TRY(hipMalloc(&s.d_wa, s.n * sizeof(float)));
         HIP_TRY(hipMalloc(&s.d_ws, s.n * sizeof(float)));
-        HIP_TRY(hipMalloc(&s.d_gain, nb * sizeof(float)));
         HIP_TRY(hipMemcpy(s.d_wa, w_analysis + off_w, s.n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.d_ws, ws.data(), s.n * sizeof(float), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(s.d_gain, gh.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+        band_gain_off.push_back(off_g);
         const int tw_key = s.log2n * 100000 + (s.kern ? s.kern->lanes : 0);   // layout depends on points per lane
         auto it = p->tw.find(tw_key);
         if (it == p->tw.end()) {
@@ -431,6 +447,27 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         HIP_TRY(hipEventCreate(&s.ev1));
         off_w += s.n;
         off_g += nb;
+    }
+    // per-bin gain lists of the (possibly merged) launches: gain[q][k] = q-th non-zero half-gain of bin k, band order
+    for (int b = 0; b < n_bands; ++b) {
+        BandState& s = p->bands[b];
+        if (s.group_size == 0) continue;
+        const int nb = s.n / 2 + 1;
+        std::vector<int> count(nb, 0);
+        int slots = 1;
+        for (int m = b; m < b + s.group_size; ++m)
+            for (int k = 0; k < nb; ++k)
+                if (gain[band_gain_off[m] + k] != 0.f && ++count[k] > slots) slots = count[k];
+        std::vector<float> table((size_t)slots * nb, 0.f);
+        std::fill(count.begin(), count.end(), 0);
+        for (int m = b; m < b + s.group_size; ++m)
+            for (int k = 0; k < nb; ++k) {
+                const float g = gain[band_gain_off[m] + k];
+                if (g != 0.f) table[(size_t)count[k]++ * nb + k] = 0.5f * g;
+            }
+        s.n_gain = slots;
+        HIP_TRY(hipMalloc(&s.d_gain, table.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(s.d_gain, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (p->scratch_cf) HIP_TRY(hipMalloc(&p->d_scratch, p->scratch_cf * sizeof(upx::cf)));
     *out = p;
@@ -516,6 +553,8 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
     }
     for (size_t b = 0; b < p->bands.size(); ++b) {
         BandState& s = p->bands[b];
+        s.last_wg = 0;
+        if (s.group_size == 0) continue;                              // carried by its group leader's launch
         const long long j_hi = (own_len + s.hop - 1) / s.hop;       // frames with j*hop < own_len
         const long long m_all = (t_out + s.hop - 1) / s.hop;        // hop-blocks that intersect [0, t_out)
         long long m_hi = j_hi + s.k - 1 < m_all ? j_hi + s.k - 1 : m_all;
@@ -533,6 +572,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             a.in = reinterpret_cast<const upx::cf*>(d_stereo);
             a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
             a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw_n = s.d_tw_n; a.tw_rows = s.d_tw;
+            a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
             a.z = p->d_scratch;
             a.y = a.z + (size_t)ch * s.n;
             a.yc = a.y + (size_t)ch * s.n;
@@ -568,6 +608,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         a.in = reinterpret_cast<const upx::cf*>(d_stereo);
         a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
         a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw = s.d_tw;
+        a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
         a.t_in = (int)t_in; a.t_out = (int)t_out;
         a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
         a.blocks_per_stream = (int)f;
@@ -643,6 +684,14 @@ int upx_plan_band_info(upx_plan* p, int band, int32_t* workgroups, int32_t* thre
     if (threads) *threads = s.kern ? s.kern->wg : s.big->row_wg;
     if (lds_bytes) *lds_bytes = s.kern ? s.kern->lds_bytes : s.big->row_lds;
     if (blocks_per_stream) *blocks_per_stream = s.last_f;
+    return UPX_OK;
+}
+
+int upx_plan_band_group(upx_plan* p, int band, int32_t* leader, int32_t* size) {
+    if (!p || band < 0 || band >= (int)p->bands.size()) return fail(UPX_ERR_INVALID, "upx_plan_band_group: bad argument");
+    const BandState& s = p->bands[band];
+    if (leader) *leader = s.group_leader;
+    if (size) *size = p->bands[s.group_leader].group_size;
     return UPX_OK;
 }
 

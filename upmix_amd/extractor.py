@@ -111,6 +111,12 @@ class DevicePlan:
         return {"workgroups": v[0].value, "threads": v[1].value, "lds_bytes": v[2].value,
                 "blocks_per_stream": v[3].value}
 
+    def band_group(self, band: int):
+        """(leader, size) of the merged launch that carries `band`."""
+        a, b = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.upx_plan_band_group(self.handle, int(band), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def set_blocks_per_stream(self, blocks: int, band: int = -1) -> None:
         _lib.check(self._lib.upx_plan_set_blocks_per_stream(self.handle, int(band), int(blocks)))
 
