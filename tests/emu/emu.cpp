@@ -99,11 +99,11 @@ int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch) {
         for (auto& v : z) v = upx::mk(NAN, NAN);
         for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step1_audio<B>(a, g);
         rows(a.z, ch * 16);
-        for (long long g = 0; g < (long long)(ch / 2) * (B::N / 2 + 1); ++g) upx::big_mask<B>(a, g);
-        for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step1_spec<B>(a.y, a.tw_n, ch, g);
+        for (long long g = 0; g < (long long)(ch / 2) * 16 * (B::N2 / 2 + 1); ++g) upx::big_mask<B>(a, g);
         rows(a.y, ch * 16);
-        for (long long g = 0; g < (long long)(ch / 2) * B::N2; ++g) upx::big_step1_spec<B>(a.yc, a.tw_n, ch / 2, g);
+        for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step2_inv<B>(a.y, a.tw_n, ch, g);
         rows(a.yc, (ch / 2) * 16);
+        for (long long g = 0; g < (long long)(ch / 2) * B::N2; ++g) upx::big_step2_inv<B>(a.yc, a.tw_n, ch / 2, g);
         for (long long g = 0; g < (long long)(a.m1 - a.m0) * B::HOP; ++g) upx::big_ola<B, K>(a, g);
     }
     return 0;

@@ -6,9 +6,12 @@
 //     N = 16 * N2,  n = n1 N2 + n2,  k = k1 + 16 k2
 //     step 1  (global)  A[k1][n2] = W_N^(k1 n2) * sum_n1 x[n1 N2 + n2] W_16^(n1 k1)
 //     step 2  (LDS)     X[k1 + 16 k2] = FFT_N2 over n2 of A[k1][.]     (row k1, reuses Stream<>)
-// so bin k lives at scratch offset (k & 15) N2 + (k >> 4).  Frames are processed
-// in chunks of CH frames (scratch stays L2/MALL resident):
-//     step1(audio*w_A) -> rows -> mask -> step1,rows on Ls+iRs -> step1,rows on Ca+iCb -> overlap-add
+// so bin k lives at scratch offset (k & 15) N2 + (k >> 4).  The inverse transforms run the
+// transposed (decimation-in-time) order on that same layout,
+//     rows (FFT_N2 over k2 of row k1)  ->  x[n1 N2 + n2] = sum_k1 W_16^(k1 n1) W_N^(k1 n2) row_k1[n2]
+// and therefore end in NATURAL time order: every kernel reads and writes coalesced.
+// Frames are processed in chunks of CH frames (scratch stays L2/MALL resident):
+//     step1(audio*w_A) -> rows -> mask -> rows,step2 on Ls+iRs -> rows,step2 on Ca+iCb -> overlap-add
 // with the same conventions as the fused kernel (upx_core.h): frame pairs
 // (odd j, j+1) share one centre transform, inverse by re/im swap, contributions
 // added in increasing j in float32, bands summed in list order.
@@ -29,7 +32,7 @@ struct BigArgs {
     const cf* tw_n;        // W_N^(k1 n2), [16][N2]
     const cf* tw_rows;     // compact twiddle table of the N2-point row transform
     cf* z;                 // scratch [CH][N]: forward spectra (bin k at (k&15) N2 + (k>>4))
-    cf* y;                 // scratch [CH][N]: Ls + i Rs spectra (natural k), then their time signals (scrambled n)
+    cf* y;                 // scratch [CH][N]: Ls + i Rs spectra (same layout as z), then their time signals (natural n)
     cf* yc;                // scratch [CH/2][N]: Ca + i Cb spectra, then time signals
     int t_in, t_out;
     int j_lo, j_hi;        // frames that exist
@@ -74,19 +77,19 @@ UPX_HD void big_step1_audio(const BigArgs& a, long long gid) {
     for (int k1 = 0; k1 < 16; ++k1) dst[k1 * N2 + n2] = k1 == 0 ? v[0] : cmul(v[k1], a.tw_n[k1 * N2 + n2]);
 }
 
-// ---- step 1 on a spectrum buffer (inverse transforms), in place ---------------------------
+// ---- last step of the inverse transforms: twiddle, radix-16 over k1; natural order out, in place ----
 template <class B>
-UPX_HD void big_step1_spec(cf* buf, const cf* tw_n, int frames, long long gid) {
+UPX_HD void big_step2_inv(cf* buf, const cf* tw_n, int frames, long long gid) {
     constexpr int N2 = B::N2, N = B::N;
     const int jj = (int)(gid / N2), n2 = (int)(gid % N2);
     if (jj >= frames) return;
     cf* p = buf + (size_t)jj * N;
     cf v[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) v[n1] = p[n1 * N2 + n2];
+    for (int k1 = 0; k1 < 16; ++k1) v[k1] = k1 == 0 ? p[n2] : cmul(p[k1 * N2 + n2], tw_n[k1 * N2 + n2]);
     Dft<16>::run(v);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; ++k1) p[k1 * N2 + n2] = k1 == 0 ? v[0] : cmul(v[k1], tw_n[k1 * N2 + n2]);
+    for (int n1 = 0; n1 < 16; ++n1) p[n1 * N2 + n2] = v[n1];
 }
 
 // ---- step 2: N2-point transforms of the rows, in LDS; one workgroup per row ----------------
@@ -115,20 +118,27 @@ UPX_HD void big_rows_program(Ex& ex, cf* buf, const cf* tw_global, cf* lds_all, 
     });
 }
 
-// ---- mask: one thread per (frame pair, bin k in [0, N/2]) ----------------------------------
+// ---- mask: one thread per (frame pair, k1, k2 <= N2/2), i.e. in the storage order of z ----------
+// bin k = k1 + 16 k2 sits at k1 N2 + k2; its partner N-k at ((16-k1)&15) N2 + (N2 - k2 - (k1 != 0)) & (N2-1):
+// consecutive threads read and write consecutive addresses (the partner side in reverse).
 template <class B>
 UPX_HD void big_mask(const BigArgs& a, long long gid) {
-    constexpr int N = B::N, NB = N / 2 + 1;
-    const int pp = (int)(gid / NB), k = (int)(gid % NB);
+    constexpr int N = B::N, N2 = B::N2, HALF = N2 / 2 + 1;
+    const int k2 = (int)(gid % HALF);
+    const int k1 = (int)((gid / HALF) % 16);
+    const int pp = (int)(gid / (16 * HALF));
     if (pp >= a.ch / 2) return;
+    const int k = k1 + 16 * k2;
+    if (k > N / 2) return;                       // the upper half is written by the partners
     const int km = (N - k) & (N - 1);           // partner bin; k = 0 and k = N/2 pair with themselves
     const bool self = km == k;
+    const int ok = B::scr(k), om = B::scr(km);
     cf c2[2];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const size_t f = (size_t)(2 * pp + half) * N;
-        const cf za = a.z[f + B::scr(k)];
-        const cf zb = self ? za : a.z[f + B::scr(km)];
+        const cf za = a.z[f + ok];
+        const cf zb = self ? za : a.z[f + om];
         const cf l0 = mk(za.x + zb.x, za.y - zb.y), r0 = mk(za.y + zb.y, zb.x - za.x);
         cf c = mk(0.f, 0.f), ls = c, rs = c;
         for (int q = 0; q < a.n_gain; ++q) {
@@ -141,16 +151,16 @@ UPX_HD void big_mask(const BigArgs& a, long long gid) {
         }
         const cf yk = mk(ls.x - rs.y, ls.y + rs.x);
         const cf ym = mk(ls.x + rs.y, rs.x - ls.y);
-        a.y[f + k] = cswap(yk);
-        if (!self) a.y[f + km] = cswap(ym);
+        a.y[f + ok] = cswap(yk);
+        if (!self) a.y[f + om] = cswap(ym);
         c2[half] = c;
     }
     const cf ca = c2[0], cb = c2[1];
     const cf ck = mk(ca.x - cb.y, ca.y + cb.x);
     const cf cm = mk(ca.x + cb.y, cb.x - ca.y);
     const size_t fc = (size_t)pp * N;
-    a.yc[fc + k] = cswap(ck);
-    if (!self) a.yc[fc + km] = cswap(cm);
+    a.yc[fc + ok] = cswap(ck);
+    if (!self) a.yc[fc + om] = cswap(cm);
 }
 
 // ---- overlap-add of the chunk's frames into the output planes; one thread per sample -------
@@ -168,7 +178,7 @@ UPX_HD void big_ola(const BigArgs& a, long long gid) {
         const int jj = j - a.j0;                        // always inside the chunk for emitted blocks
         const int idx = (int)(n - (long long)j * HOP);
         const float w = a.w_s[idx];
-        const int o = B::scr(idx);
+        const int o = idx;                              // inverse transforms end in natural order
         const cf lr = a.y[(size_t)jj * N + o];
         const cf cc = a.yc[(size_t)(jj >> 1) * N + o];
         acc_l += lr.y * w;                              // swapped outputs: Re = .y, Im = .x

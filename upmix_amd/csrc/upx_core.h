@@ -485,18 +485,21 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             old_r[s] = a.accumulate ? out_r[nc] : 0.f;
 #endif
         }
+        // synthesis window: fetched before the final pass so the L2 latency hides behind the butterflies
+        const UPX_GLOBAL float* w_s = opaque(a.w_s);
+        float w[P];
+#pragma unroll
+#if defined(UPX_EXP) && UPX_EXP >= 3
+        for (int s = 0; s < P; ++s) w[s] = 0.001f;
+#else
+        for (int s = 0; s < P; ++s) w[s] = opaque(w_s + s * LANES)[lane];
+#endif
         S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
         S::template pass_compute<LAST>(th, tw, lane);
-        const UPX_GLOBAL float* w_s = opaque(a.w_s);
 #pragma unroll
         for (int s = 0; s < P; ++s) {
-#if defined(UPX_EXP) && UPX_EXP >= 3
-            const float w = 0.001f;
-#else
-            const float w = opaque(w_s + s * LANES)[lane];
-#endif
-            th.acc_l[s] += th.x[s].y * w;   // swapped output: Re y = x.y, Im y = x.x
-            th.acc_r[s] += th.x[s].x * w;
+            th.acc_l[s] += th.x[s].y * w[s];   // swapped output: Re y = x.y, Im y = x.x
+            th.acc_r[s] += th.x[s].x * w[s];
         }
 #pragma unroll
         for (int s = 0; s < HS; ++s) {
@@ -539,8 +542,6 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #endif
             }
         }
-        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
-        S::template pass_compute<LAST>(th, tw, lane);
         const UPX_GLOBAL float* w_s = opaque(a.w_s);
         float w[P];
 #pragma unroll
@@ -549,6 +550,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #else
         for (int s = 0; s < P; ++s) w[s] = opaque(w_s + s * LANES)[lane];
 #endif
+        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
+        S::template pass_compute<LAST>(th, tw, lane);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int j = ja + half;

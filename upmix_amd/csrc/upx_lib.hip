@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256) void upx_big_step1_audio_kernel(upx::BigArgs a
     upx::big_step1_audio<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 template <class B>
-__global__ __launch_bounds__(256) void upx_big_step1_spec_kernel(upx::cf* buf, const upx::cf* tw_n, int frames) {
-    upx::big_step1_spec<B>(buf, tw_n, frames, (long long)blockIdx.x * 256 + threadIdx.x);
+__global__ __launch_bounds__(256) void upx_big_step2_inv_kernel(upx::cf* buf, const upx::cf* tw_n, int frames) {
+    upx::big_step2_inv<B>(buf, tw_n, frames, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 template <class B>
 __global__ __launch_bounds__(B::Row::WG) void upx_big_rows_kernel(upx::cf* buf, const upx::cf* tw_rows) {
@@ -164,11 +164,11 @@ struct BigImpl {
         const int ch = a.ch;
         hipLaunchKernelGGL(upx_big_step1_audio_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3(ch * 16), dim3(Row::WG), kRowLds, st, a.z, a.tw_rows);
-        hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks((long long)(ch / 2) * (B::N / 2 + 1))), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(upx_big_step1_spec_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a.y, a.tw_n, ch);
+        hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks((long long)(ch / 2) * 16 * (B::N2 / 2 + 1))), dim3(256), 0, st, a);
         hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3(ch * 16), dim3(Row::WG), kRowLds, st, a.y, a.tw_rows);
-        hipLaunchKernelGGL(upx_big_step1_spec_kernel<B>, dim3(blocks((long long)(ch / 2) * B::N2)), dim3(256), 0, st, a.yc, a.tw_n, ch / 2);
+        hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a.y, a.tw_n, ch);
         hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3((ch / 2) * 16), dim3(Row::WG), kRowLds, st, a.yc, a.tw_rows);
+        hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)(ch / 2) * B::N2)), dim3(256), 0, st, a.yc, a.tw_n, ch / 2);
         hipLaunchKernelGGL((upx_big_ola_kernel<B, K>), dim3(blocks((long long)(a.m1 - a.m0) * B::HOP)), dim3(256), 0, st, a);
     }
     static int prepare() {
