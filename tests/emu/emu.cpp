@@ -70,47 +70,63 @@ extern "C" int emu_band(int log2n, int k_overlap, int pts, const float* in, long
     return -1;
 }
 
-// ---- large STFT sizes (four-step transform through scratch), same chunk loop as the library ----
+// ---- unfused path (large STFT sizes and arbitrary hops), same chunk loop as the library ----------
 namespace {
-template <class B, int K>
-int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch) {
+template <class B>
+int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch_max) {
     using Row = typename B::Row;
     std::vector<upx::cf> tw_n((size_t)B::N), tw_rows((size_t)Row::TW_CF);
-    upx::fill_big_twiddles<B>(tw_n.data(), turn_trig);
+    if (B::N1 == 16) upx::fill_big_twiddles<B>(tw_n.data(), turn_trig);
     upx::fill_twiddles<Row>(tw_rows.data(), turn_trig);
+    // chunk geometry: halo frames (odd count so that every chunk starts on an odd frame), emitted blocks (even),
+    // plus one trailing pair-partner frame
+    const int halo = (a.kf - 1) | 1;
+    int emit = (ch_max - halo - 1) & ~1;
+    if (emit < 2) emit = 2;
+    const int ch = emit + halo + 1;
     std::vector<upx::cf> z((size_t)ch * B::N), y((size_t)ch * B::N), yc((size_t)(ch / 2) * B::N);
     std::vector<upx::cf> lds((size_t)Row::LDS_CF);
     a.tw_n = tw_n.data(); a.tw_rows = tw_rows.data();
     a.z = z.data(); a.y = y.data(); a.yc = yc.data();
     a.ch = ch;
-    const int emit = ch - K;   // even; the last frame of a chunk only serves as a pair partner
     auto rows = [&](upx::cf* buf, int n_rows) {
-        for (int r = 0; r < n_rows; ++r) {
+        for (int wg = 0; wg < (n_rows + Row::G - 1) / Row::G; ++wg) {
             SeqExec<Row::P> ex;
             ex.st.resize(Row::WG);
             for (auto& v : lds) v = upx::mk(NAN, NAN);
-            upx::big_rows_program<B>(ex, buf, a.tw_rows, lds.data(), r);
+            upx::big_rows_program<B>(ex, buf, a.tw_rows, lds.data(), wg, n_rows);
         }
     };
     for (int m0 = m_lo; m0 < m_hi; m0 += emit) {
-        a.j0 = m0 - (K - 1);
+        a.j0 = m0 - halo;
         a.m0 = m0;
         a.m1 = m0 + emit < m_hi ? m0 + emit : m_hi;
         for (auto& v : z) v = upx::mk(NAN, NAN);
-        for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step1_audio<B>(a, g);
-        rows(a.z, ch * 16);
-        for (long long g = 0; g < (long long)(ch / 2) * 16 * (B::N2 / 2 + 1); ++g) upx::big_mask<B>(a, g);
-        rows(a.y, ch * 16);
-        for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step2_inv<B>(a.y, a.tw_n, ch, g);
-        rows(a.yc, (ch / 2) * 16);
-        for (long long g = 0; g < (long long)(ch / 2) * B::N2; ++g) upx::big_step2_inv<B>(a.yc, a.tw_n, ch / 2, g);
-        for (long long g = 0; g < (long long)(a.m1 - a.m0) * B::HOP; ++g) upx::big_ola<B, K>(a, g);
+        if (B::N1 == 16) {
+            for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step1_audio<B>(a, g);
+            rows(a.z, ch * 16);
+        } else {
+            for (int wg = 0; wg < (ch + Row::G - 1) / Row::G; ++wg) {
+                SeqExec<Row::P> ex;
+                ex.st.resize(Row::WG);
+                for (auto& v : lds) v = upx::mk(NAN, NAN);
+                upx::big_frame_program<B>(ex, a, lds.data(), wg);
+            }
+        }
+        for (long long g = 0; g < upx::big_mask_threads<B>(ch / 2); ++g) upx::big_mask<B>(a, g);
+        rows(a.y, ch * B::N1);
+        rows(a.yc, (ch / 2) * B::N1);
+        if (B::N1 == 16) {
+            for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step2_inv<B>(a.y, a.tw_n, ch, g);
+            for (long long g = 0; g < (long long)(ch / 2) * B::N2; ++g) upx::big_step2_inv<B>(a.yc, a.tw_n, ch / 2, g);
+        }
+        for (long long g = 0; g < (long long)(a.m1 - a.m0) * a.hop; ++g) upx::big_ola<B>(a, g);
     }
     return 0;
 }
 }   // namespace
 
-extern "C" int emu_big_band(int log2n, int k_overlap, const float* in, long long t_in, float* out_c, float* out_l,
+extern "C" int emu_big_band(int log2n, int hop, const float* in, long long t_in, float* out_c, float* out_l,
                             float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
                             const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int chunk_frames,
                             int accumulate, int n_gain) {
@@ -120,10 +136,11 @@ extern "C" int emu_big_band(int log2n, int k_overlap, const float* in, long long
     a.out_c = out_c; a.out_l = out_l; a.out_r = out_r;
     a.w_a = w_a; a.w_s = w_s_scaled; a.gain = gain_half;
     a.t_in = (int)t_in; a.t_out = (int)t_out;
+    a.hop = hop; a.kf = ((1 << log2n) + hop - 1) / hop;
     a.j_lo = j_lo; a.j_hi = j_hi; a.accumulate = accumulate;
     a.n_gain = n_gain; a.gain_stride = (1 << log2n) / 2 + 1;
-#define UPX_BIG(L, K) if (log2n == L && k_overlap == K) return run_big<upx::BigCfg<L, K>, K>(a, m_lo, m_hi, chunk_frames);
-    UPX_BIG(14, 4) UPX_BIG(15, 4) UPX_BIG(16, 4) UPX_BIG(14, 2) UPX_BIG(14, 8)
+#define UPX_BIG(L) if (log2n == L) return run_big<upx::BigCfg<L>>(a, m_lo, m_hi, chunk_frames);
+    UPX_BIG(8) UPX_BIG(9) UPX_BIG(10) UPX_BIG(11) UPX_BIG(12) UPX_BIG(13) UPX_BIG(14) UPX_BIG(15) UPX_BIG(16)
 #undef UPX_BIG
     return -1;
 }

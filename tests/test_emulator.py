@@ -145,32 +145,51 @@ def test_silence_is_exact_zero(emu):
     assert all(not g.any() for g in got)
 
 
+def run_unfused(emu, band, x, ch):
+    emu.emu_big_band.argtypes = [ctypes.c_int, ctypes.c_int, fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong,
+                                 fp, fp, fp] + [ctypes.c_int] * 7
+    n, hop, total = band.block_size, band.hop_size, len(x)
+    blocks = -(-total // hop)
+    w_a = np.ascontiguousarray(band.analysis_window)
+    w_s = (band.synthesis_window / np.float32(n)).astype(np.float32)
+    gain = (0.5 * orc.band_gain(band)).astype(np.float32)
+    outs = [np.full(total, np.nan, np.float32) for _ in range(3)]
+    xin = np.ascontiguousarray(x)
+    rc = emu.emu_big_band(int(np.log2(n)), hop, P(xin), total, P(outs[0]), P(outs[1]), P(outs[2]), total, P(w_a),
+                          P(w_s), P(gain), 0, blocks, 0, blocks, ch, 0, 1)
+    assert rc == 0
+    return outs
+
+
 def test_large_stft_four_step_path(emu):
     """STFT 16384..65536 (upx_big.h): chunked four-step transform, vs the oracle."""
     if PTS[0] != 16:
-        pytest.skip("the four-step path has one build")
-    emu.emu_big_band.argtypes = [ctypes.c_int, ctypes.c_int, fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong,
-                                 fp, fp, fp] + [ctypes.c_int] * 7
+        pytest.skip("the unfused path has one build")
     for n, total, ch, lo, hi, wl, wh, ov in ((16384, 70000, 8, 120., 480., 30., 120., 0.75),
                                              (65536, 150000, 6, 0., 30., 0., 7.5, 0.75),
                                              (32768, 100000, 8, 30., 120., 7.5, 30., 0.75),
                                              (16384, 50000, 6, 120., 480., 30., 120., 0.5)):
         band = orc.Band(n, ov, lo, hi, 48000, "raised_cosine", wl, wh)
-        k = n // band.hop_size
         x = orc.synthetic_stereo(total, n)
         ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
-        frames = -(-total // band.hop_size)
-        w_a = np.ascontiguousarray(band.analysis_window)
-        w_s = (band.synthesis_window / np.float32(n)).astype(np.float32)
-        gain = (0.5 * orc.band_gain(band)).astype(np.float32)
-        outs = [np.full(total, np.nan, np.float32) for _ in range(3)]
-        xin = np.ascontiguousarray(x)
-        rc = emu.emu_big_band(int(np.log2(n)), k, P(xin), total, P(outs[0]), P(outs[1]), P(outs[2]), total, P(w_a),
-                              P(w_s), P(gain), 0, frames, 0, frames, ch, 0, 1)
-        assert rc == 0
-        for g, r in zip(outs, ref):
+        for g, r in zip(run_unfused(emu, band, x, ch), ref):
             assert not np.isnan(g).any()
             assert rms(g.astype(np.float64) - r) < 1e-7, n
+
+
+def test_arbitrary_hops_unfused_path(emu):
+    """Hops that do not divide N (hop = int(N (1 - overlap)), center_extraction.py:252) and K = 16."""
+    if PTS[0] != 16:
+        pytest.skip("the unfused path has one build")
+    for n, ov, wname, total, ch in ((512, 0.6, "hamming", 6000, 12), (1024, 0.7, "hann", 9000, 10),
+                                    (256, 0.9375, "hann", 3000, 40), (2048, 0.35, "sqrt_hann", 12000, 6),
+                                    (4096, 0.8, "blackman_harris", 30000, 12), (16384, 0.6, "hann", 80000, 8)):
+        band = orc.Band(n, ov, 200., 8000., 44100, "raised_cosine", 50., 2000., window=orc.WINDOWS[wname])
+        x = orc.synthetic_stereo(total, n + 1)
+        ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+        for g, r in zip(run_unfused(emu, band, x, ch), ref):
+            assert not np.isnan(g).any()
+            assert rms(g.astype(np.float64) - r) < 1e-7, (n, ov, band.hop_size)
 
 
 def merged_gain_table(bands):

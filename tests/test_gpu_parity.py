@@ -84,16 +84,44 @@ def test_golden_other_overlaps_and_windows(ux):
 
 def test_unsupported_shapes_fail_loudly(ux):
     x = np.zeros((4000, 2), np.float32)
-    # hop = int(512 * 0.4) = 204 does not divide N: not covered by the kernels
-    bex = ux.MultiBandExtractorAccu(512, 0.6, ux.make_hamming, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
-    with pytest.raises(NotImplementedError):
-        bex.process_all_blocks(x[:, 0], x[:, 1])
     # sizes outside 256..65536 are not covered
     bex = ux.MultiBandExtractorAccu(128, 0.75, ux.make_hann, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
     with pytest.raises(NotImplementedError):
         bex.process_all_blocks(x[:, 0], x[:, 1])
+    # more than 64 frames overlapping one sample (hop = 2 of 256) is refused, not silently slow
+    bex = ux.MultiBandExtractorAccu(256, 0.995, ux.make_hann, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
+    with pytest.raises(NotImplementedError):
+        bex.process_all_blocks(x[:, 0], x[:, 1])
     with pytest.raises(ValueError):
         ux.MultiBandExtractorAccu(4, 0.9, ux.make_hann, 0.0, 100.0, 48000)
+
+
+def test_arbitrary_overlap_unfused_path(ux, orc, monkeypatch):
+    """hop = int(N (1 - overlap)) that does not divide N, K = 16, and the unfused path forced."""
+    z = load_golden("f4_oneband.npz")
+    bex = ux.MultiBandExtractorAccu(512, 0.6, ux.make_hamming, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
+    assert bex.hop_size == 204
+    x = z["ov60_hamming_x"]
+    for got, k in zip(bex.process_all_blocks(x[:, 0], x[:, 1]), "clr"):
+        close(got, z[f"ov60_hamming_{k}"])
+    x = orc.synthetic_stereo(300000, 13)
+    for n, ov, wname in ((1024, 0.7, "hann"), (256, 0.9375, "hann"), (2048, 0.35, "sqrt_hann"),
+                         (4096, 0.8, "blackman_harris"), (8192, 0.9, "blackman"), (16384, 0.6, "hann")):
+        gb = ux.MultiBandExtractorAccu(n, ov, ux.WINDOW_FUNCS[wname], 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
+        ob = orc.Band(n, ov, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0, window=orc.WINDOWS[wname])
+        ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+        for got, r in zip(gb.process_all_blocks(x[:, 0], x[:, 1]), ref):
+            close(got, r)
+    # the unfused pipeline on a plan the fused kernels normally take (merged bands included)
+    monkeypatch.setenv("UPX_FORCE_UNFUSED", "1")
+    bands = gpu_chain(ux, [0, 30, 120, 480, 1920, 7680], 48000, 8192, 32)
+    ob = orc.plan_bands([0, 30, 120, 480, 1920, 7680], 0.75, orc.win_blackman_harris, 48000, max_block_size=8192)
+    x = orc.synthetic_stereo(200000, 14)
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+    plan = ux.DevicePlan(bands)
+    for got, r in zip(plan.process(x), ref):
+        close(got, r)
+    plan.close()
 
 
 def test_golden_multi_band(ux):

@@ -138,7 +138,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.upx_abi_version() == 1
     assert lib.upx_supported(8192, 2048) == 1 and lib.upx_supported(65536, 16384) == 1
     assert lib.upx_supported(131072, 32768) == 0 and lib.upx_supported(128, 32) == 0
-    assert lib.upx_supported(512, 204) == 0
+    assert lib.upx_supported(512, 204) == 1 and lib.upx_supported(256, 2) == 0   # any hop, <= 64 frames per sample
 
 
 def test_no_cpu_fallback_in_product(monkeypatch):

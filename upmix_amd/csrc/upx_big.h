@@ -15,6 +15,9 @@
 // with the same conventions as the fused kernel (upx_core.h): frame pairs
 // (odd j, j+1) share one centre transform, inverse by re/im swap, contributions
 // added in increasing j in float32, bands summed in list order.
+// The same unfused pipeline (with N1 = 1, i.e. the whole frame transform inside one LDS row) also
+// serves every STFT size when the hop is NOT N/2, N/4 or N/8 (e.g. overlap 0.6 -> hop = int(0.4 N),
+// center_extraction.py:252): hop and the number of frames covering a sample are run-time values here.
 #pragma once
 #include "upx_core.h"
 
@@ -35,6 +38,8 @@ struct BigArgs {
     cf* y;                 // scratch [CH][N]: Ls + i Rs spectra (same layout as z), then their time signals (natural n)
     cf* yc;                // scratch [CH/2][N]: Ca + i Cb spectra, then time signals
     int t_in, t_out;
+    int hop;               // frame advance in samples (any value in [1, N])
+    int kf;                // frames that cover one sample: ceil(N / hop)
     int j_lo, j_hi;        // frames that exist
     int j0;                // first frame of the chunk (odd): chunk frames j0 .. j0+ch-1
     int ch;                // frames in the chunk (even)
@@ -42,13 +47,15 @@ struct BigArgs {
     int accumulate;
 };
 
-template <int LOG2N, int K>
+template <int LOG2N>
 struct BigCfg {
     static constexpr int N = 1 << LOG2N;
-    static constexpr int N2 = N / 16;
-    static constexpr int HOP = N / K;
-    using Row = Cfg<LOG2N - 4, 4, 16>;   // the N2-point row transform (K unused there)
-    UPX_HD static int scr(int i) { return (i & 15) * N2 + (i >> 4); }   // index -> scratch offset after a four-step transform
+    static constexpr int N1 = LOG2N >= 14 ? 16 : 1;      // radix of the global step (1: the frame fits one LDS row)
+    static constexpr int N2 = N / N1;
+    static constexpr int LOG2N2 = LOG2N >= 14 ? LOG2N - 4 : LOG2N;
+    using Row = Cfg<LOG2N2, 4, 16>;                      // the N2-point row transform (its K is unused)
+    // bin k -> scratch offset after the forward transform
+    UPX_HD static int scr(int i) { return N1 == 1 ? i : (i & 15) * N2 + (i >> 4); }
 };
 
 // ---- step 1 on audio: window, radix-16 over n1, twiddle; one thread per (frame, n2) ----
@@ -63,7 +70,7 @@ UPX_HD void big_step1_audio(const BigArgs& a, long long gid) {
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         const int o = n1 * N2 + n2;
-        const long long n = (long long)j * B::HOP + o;
+        const long long n = (long long)j * a.hop + o;
         v[n1] = mk(0.f, 0.f);
         if (exists && n >= 0 && n < a.t_in) {
             const cf s = a.in[n];
@@ -94,27 +101,73 @@ UPX_HD void big_step2_inv(cf* buf, const cf* tw_n, int frames, long long gid) {
 
 // ---- step 2: N2-point transforms of the rows, in LDS; one workgroup per row ----------------
 // rows are contiguous [N2] complex; row r of the buffer starts at r * N2.
+// A workgroup carries G = WG/LANES rows (more than one only when a row needs less than a wave).
 template <class B, class Ex>
-UPX_HD void big_rows_program(Ex& ex, cf* buf, const cf* tw_global, cf* lds_all, int row) {
+UPX_HD void big_rows_program(Ex& ex, cf* buf, const cf* tw_global, cf* lds_all, int wg_index, int n_rows) {
     using C = typename B::Row;
     using S = Stream<C>;
     using Thread = ThreadT<C::P>;
     constexpr int LANES = C::LANES, P = C::P;
     cf* const tw = lds_all + C::G * C::PITCH;
-    cf* const data = buf + (size_t)row * C::N;
     ex.each([&](int tid, Thread& th) {
         for (int i = tid; i < C::TW_CF; i += C::WG) tw[i] = tw_global[i];
+        const int row = wg_index * C::G + tid / LANES, lane = tid % LANES;
+        const cf* data = buf + (size_t)row * C::N;
 #pragma unroll
-        for (int s = 0; s < P; ++s) th.x[s] = data[tid + s * LANES];
-        S::template pass_compute<0>(th, tw, tid);
+        for (int s = 0; s < P; ++s) th.x[s] = row < n_rows ? data[lane + s * LANES] : mk(0.f, 0.f);
+        S::template pass_compute<0>(th, tw, lane);
     });
-    ex.each([&](int tid, Thread& th) { S::template pass_write<0>(th, lds_all, tid); });
+    ex.each([&](int tid, Thread& th) { S::template pass_write<0>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
     S::template mid_passes<1>(ex, lds_all, tw);
     ex.each([&](int tid, Thread& th) {
-        S::read_all(th, lds_all, tid);
-        S::template pass_compute<C::PS::n - 1>(th, tw, tid);
+        const int row = wg_index * C::G + tid / LANES, lane = tid % LANES;
+        cf* data = buf + (size_t)row * C::N;
+        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
+        S::template pass_compute<C::PS::n - 1>(th, tw, lane);
+        if (row < n_rows) {
 #pragma unroll
-        for (int s = 0; s < P; ++s) data[tid + s * LANES] = th.x[s];
+            for (int s = 0; s < P; ++s) data[lane + s * LANES] = th.x[s];
+        }
+    });
+}
+
+// ---- N1 == 1: window + whole-frame transform in one LDS row; G frames per workgroup ----------------
+template <class B, class Ex>
+UPX_HD void big_frame_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index) {
+    using C = typename B::Row;
+    using S = Stream<C>;
+    using Thread = ThreadT<C::P>;
+    constexpr int LANES = C::LANES, P = C::P;
+    cf* const tw = lds_all + C::G * C::PITCH;
+    ex.each([&](int tid, Thread& th) {
+        for (int i = tid; i < C::TW_CF; i += C::WG) tw[i] = a.tw_rows[i];
+        const int jj = wg_index * C::G + tid / LANES, lane = tid % LANES;
+        const int j = a.j0 + jj;
+        const bool exists = jj < a.ch && j >= a.j_lo && j < a.j_hi;
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const int o = lane + s * LANES;
+            const long long n = (long long)j * a.hop + o;
+            th.x[s] = mk(0.f, 0.f);
+            if (exists && n >= 0 && n < a.t_in) {
+                const cf v = a.in[n];
+                const float w = a.w_a[o];
+                th.x[s] = mk(v.x * w, v.y * w);
+            }
+        }
+        S::template pass_compute<0>(th, tw, lane);
+    });
+    ex.each([&](int tid, Thread& th) { S::template pass_write<0>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+    S::template mid_passes<1>(ex, lds_all, tw);
+    ex.each([&](int tid, Thread& th) {
+        const int jj = wg_index * C::G + tid / LANES, lane = tid % LANES;
+        cf* data = a.z + (size_t)jj * C::N;
+        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
+        S::template pass_compute<C::PS::n - 1>(th, tw, lane);
+        if (jj < a.ch) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) data[lane + s * LANES] = th.x[s];
+        }
     });
 }
 
@@ -122,13 +175,24 @@ UPX_HD void big_rows_program(Ex& ex, cf* buf, const cf* tw_global, cf* lds_all, 
 // bin k = k1 + 16 k2 sits at k1 N2 + k2; its partner N-k at ((16-k1)&15) N2 + (N2 - k2 - (k1 != 0)) & (N2-1):
 // consecutive threads read and write consecutive addresses (the partner side in reverse).
 template <class B>
+UPX_HD long long big_mask_threads(int pairs) {
+    return B::N1 == 1 ? (long long)pairs * (B::N / 2 + 1) : (long long)pairs * 16 * (B::N2 / 2 + 1);
+}
+template <class B>
 UPX_HD void big_mask(const BigArgs& a, long long gid) {
-    constexpr int N = B::N, N2 = B::N2, HALF = N2 / 2 + 1;
-    const int k2 = (int)(gid % HALF);
-    const int k1 = (int)((gid / HALF) % 16);
-    const int pp = (int)(gid / (16 * HALF));
+    constexpr int N = B::N, N2 = B::N2;
+    int pp, k;
+    if (B::N1 == 1) {                            // natural layout: one thread per bin
+        pp = (int)(gid / (N / 2 + 1));
+        k = (int)(gid % (N / 2 + 1));
+    } else {
+        constexpr int HALF = N2 / 2 + 1;
+        const int k2 = (int)(gid % HALF);
+        const int k1 = (int)((gid / HALF) % 16);
+        pp = (int)(gid / (16 * HALF));
+        k = k1 + 16 * k2;
+    }
     if (pp >= a.ch / 2) return;
-    const int k = k1 + 16 * k2;
     if (k > N / 2) return;                       // the upper half is written by the partners
     const int km = (N - k) & (N - 1);           // partner bin; k = 0 and k = N/2 pair with themselves
     const bool self = km == k;
@@ -164,23 +228,24 @@ UPX_HD void big_mask(const BigArgs& a, long long gid) {
 }
 
 // ---- overlap-add of the chunk's frames into the output planes; one thread per sample -------
-template <class B, int K>
+template <class B>
 UPX_HD void big_ola(const BigArgs& a, long long gid) {
-    constexpr int N = B::N, HOP = B::HOP;
-    const long long n = (long long)a.m0 * HOP + gid;
-    if (n >= (long long)a.m1 * HOP || n >= a.t_out) return;
-    const int m = (int)(n / HOP);
+    constexpr int N = B::N;
+    const long long n = (long long)a.m0 * a.hop + gid;
+    if (n >= (long long)a.m1 * a.hop || n >= a.t_out) return;
+    // frames covering n: j*hop <= n < j*hop + N, increasing j (the reference's accumulation order)
+    long long j_first = (n - N + a.hop) / a.hop;     // ceil((n - N + 1) / hop) for n - N + 1 > 0
+    if (n - N + 1 <= 0) j_first = 0;
+    if (j_first < a.j_lo) j_first = a.j_lo;
+    long long j_last = n / a.hop;
+    if (j_last >= a.j_hi) j_last = a.j_hi - 1;
     float acc_c = 0.f, acc_l = 0.f, acc_r = 0.f;
-#pragma unroll
-    for (int d = K - 1; d >= 0; --d) {       // frames m-K+1 .. m, increasing
-        const int j = m - d;
-        if (j < a.j_lo || j >= a.j_hi) continue;       // frames that do not exist contribute exactly 0
-        const int jj = j - a.j0;                        // always inside the chunk for emitted blocks
-        const int idx = (int)(n - (long long)j * HOP);
+    for (long long j = j_first; j <= j_last; ++j) {
+        const int jj = (int)(j - a.j0);                  // inside the chunk for every emitted block
+        const int idx = (int)(n - j * a.hop);
         const float w = a.w_s[idx];
-        const int o = idx;                              // inverse transforms end in natural order
-        const cf lr = a.y[(size_t)jj * N + o];
-        const cf cc = a.yc[(size_t)(jj >> 1) * N + o];
+        const cf lr = a.y[(size_t)jj * N + idx];        // inverse transforms end in natural order
+        const cf cc = a.yc[(size_t)(jj >> 1) * N + idx];
         acc_l += lr.y * w;                              // swapped outputs: Re = .y, Im = .x
         acc_r += lr.x * w;
         acc_c += ((jj & 1) == 0 ? cc.y : cc.x) * w;

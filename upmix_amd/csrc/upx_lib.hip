@@ -108,7 +108,7 @@ __global__ void upx_seam_add_kernel(float* c, float* l, float* r, const float* p
     }
 }
 
-// ---- STFT sizes 16384..65536: four-step transform through scratch (upx_big.h) ----------------
+// ---- unfused path: STFT sizes 16384..65536 and arbitrary hops (upx_big.h) ---------------------
 template <class B>
 __global__ __launch_bounds__(256) void upx_big_step1_audio_kernel(upx::BigArgs a) {
     upx::big_step1_audio<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
@@ -118,22 +118,28 @@ __global__ __launch_bounds__(256) void upx_big_step2_inv_kernel(upx::cf* buf, co
     upx::big_step2_inv<B>(buf, tw_n, frames, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 template <class B>
-__global__ __launch_bounds__(B::Row::WG) void upx_big_rows_kernel(upx::cf* buf, const upx::cf* tw_rows) {
+__global__ __launch_bounds__(B::Row::WG) void upx_big_rows_kernel(upx::cf* buf, const upx::cf* tw_rows, int n_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<B::Row::WAVE_SYNC, B::Row::P> ex;
-    upx::big_rows_program<B>(ex, buf, tw_rows, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    upx::big_rows_program<B>(ex, buf, tw_rows, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x, n_rows);
+}
+template <class B>
+__global__ __launch_bounds__(B::Row::WG) void upx_big_frame_kernel(upx::BigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<B::Row::WAVE_SYNC, B::Row::P> ex;
+    upx::big_frame_program<B>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 template <class B>
 __global__ __launch_bounds__(256) void upx_big_mask_kernel(upx::BigArgs a) {
     upx::big_mask<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
-template <class B, int K>
+template <class B>
 __global__ __launch_bounds__(256) void upx_big_ola_kernel(upx::BigArgs a) {
-    upx::big_ola<B, K>(a, (long long)blockIdx.x * 256 + threadIdx.x);
+    upx::big_ola<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 
 struct BigEntry {
-    int n, n2, k, row_wg, row_lds, row_tw_cf;
+    int n, n1, row_wg, row_lds, row_tw_cf;
     void (*chunk)(const upx::BigArgs&, hipStream_t);
     int (*prepare)();
     void (*fill_tw_n)(upx::cf*);
@@ -154,43 +160,57 @@ void turn_trig(double frac, double& c, double& s) {
     s = std::sin(a);
 }
 
-template <class B, int K>
+template <class B>
 struct BigImpl {
     using Row = typename B::Row;
     static constexpr int kRowLds = Row::LDS_CF * (int)sizeof(upx::cf);
     static unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
+    static unsigned row_wgs(int rows) { return (unsigned)((rows + Row::G - 1) / Row::G); }
+    static void rows(upx::cf* buf, const upx::cf* tw, int n_rows, hipStream_t st) {
+        hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3(row_wgs(n_rows)), dim3(Row::WG), kRowLds, st, buf, tw, n_rows);
+    }
     // all launches of one chunk, in stream order
     static void chunk(const upx::BigArgs& a, hipStream_t st) {
         const int ch = a.ch;
-        hipLaunchKernelGGL(upx_big_step1_audio_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3(ch * 16), dim3(Row::WG), kRowLds, st, a.z, a.tw_rows);
-        hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks((long long)(ch / 2) * 16 * (B::N2 / 2 + 1))), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3(ch * 16), dim3(Row::WG), kRowLds, st, a.y, a.tw_rows);
-        hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a.y, a.tw_n, ch);
-        hipLaunchKernelGGL(upx_big_rows_kernel<B>, dim3((ch / 2) * 16), dim3(Row::WG), kRowLds, st, a.yc, a.tw_rows);
-        hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)(ch / 2) * B::N2)), dim3(256), 0, st, a.yc, a.tw_n, ch / 2);
-        hipLaunchKernelGGL((upx_big_ola_kernel<B, K>), dim3(blocks((long long)(a.m1 - a.m0) * B::HOP)), dim3(256), 0, st, a);
+        if (B::N1 == 16) {
+            hipLaunchKernelGGL(upx_big_step1_audio_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a);
+            rows(a.z, a.tw_rows, ch * 16, st);
+        } else {
+            hipLaunchKernelGGL(upx_big_frame_kernel<B>, dim3(row_wgs(ch)), dim3(Row::WG), kRowLds, st, a);
+        }
+        hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks(upx::big_mask_threads<B>(ch / 2))), dim3(256), 0, st, a);
+        rows(a.y, a.tw_rows, ch * B::N1, st);
+        rows(a.yc, a.tw_rows, (ch / 2) * B::N1, st);
+        if (B::N1 == 16) {
+            hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a.y, a.tw_n, ch);
+            hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)(ch / 2) * B::N2)), dim3(256), 0, st, a.yc, a.tw_n, ch / 2);
+        }
+        hipLaunchKernelGGL(upx_big_ola_kernel<B>, dim3(blocks((long long)(a.m1 - a.m0) * a.hop)), dim3(256), 0, st, a);
     }
     static int prepare() {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_rows_kernel<B>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kRowLds);
+        int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_rows_kernel<B>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kRowLds);
+        if (!e && B::N1 == 1)
+            e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_frame_kernel<B>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kRowLds);
+        return e;
     }
-    static void fill_n(upx::cf* tw) { upx::fill_big_twiddles<B>(tw, turn_trig); }
+    static void fill_n(upx::cf* tw) { if (B::N1 == 16) upx::fill_big_twiddles<B>(tw, turn_trig); }
     static void fill_rows(upx::cf* tw) { upx::fill_twiddles<Row>(tw, turn_trig); }
-    static BigEntry get() { return BigEntry{B::N, B::N2, K, Row::WG, kRowLds, Row::TW_CF, &chunk, &prepare, &fill_n, &fill_rows}; }
+    static BigEntry get() { return BigEntry{B::N, B::N1, Row::WG, kRowLds, Row::TW_CF, &chunk, &prepare, &fill_n, &fill_rows}; }
 };
 
-const BigEntry* find_big(int log2n, int k) {
-    static const std::map<std::pair<int, int>, BigEntry> table = [] {
-        std::map<std::pair<int, int>, BigEntry> t;
-#define UPX_BIG(L, K) t[{L, K}] = BigImpl<upx::BigCfg<L, K>, K>::get();
-        UPX_BIG(14, 2) UPX_BIG(14, 4) UPX_BIG(14, 8)
-        UPX_BIG(15, 2) UPX_BIG(15, 4) UPX_BIG(15, 8)
-        UPX_BIG(16, 2) UPX_BIG(16, 4) UPX_BIG(16, 8)
+constexpr int kMaxFramesPerSample = 64;   // unfused path: ceil(N / hop) frames overlap one sample
+
+const BigEntry* find_big(int log2n) {
+    static const std::map<int, BigEntry> table = [] {
+        std::map<int, BigEntry> t;
+#define UPX_BIG(L) t[L] = BigImpl<upx::BigCfg<L>>::get();
+        UPX_BIG(8) UPX_BIG(9) UPX_BIG(10) UPX_BIG(11) UPX_BIG(12) UPX_BIG(13) UPX_BIG(14) UPX_BIG(15) UPX_BIG(16)
 #undef UPX_BIG
         return t;
     }();
-    auto it = table.find({log2n, k});
+    auto it = table.find(log2n);
     return it == table.end() ? nullptr : &it->second;
 }
 
@@ -354,10 +374,10 @@ int upx_device_count(int* count) {
 }
 
 int upx_supported(int32_t block_size, int32_t hop) {
-    if (block_size < 1 || hop < 1 || block_size % hop) return 0;
+    if (block_size < 1 || hop < 1 || hop > block_size) return 0;
     const int l = ilog2_exact(block_size);
-    if (l < 0) return 0;
-    return (find_kernel(l, block_size / hop, 0) || find_big(l, block_size / hop)) ? 1 : 0;
+    if (l < 0 || !find_big(l)) return 0;
+    return (block_size + hop - 1) / hop <= kMaxFramesPerSample ? 1 : 0;
 }
 
 int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* block_size, const int32_t* hop,
@@ -369,7 +389,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         if (!upx_supported(block_size[b], hop[b]))
             return fail(UPX_ERR_UNSUPPORTED,
                         "band %d: STFT size %d with hop %d is not covered by the gfx950 kernels "
-                        "(power-of-two sizes 256..65536, hop = N/2, N/4 or N/8)",
+                        "(power-of-two sizes 256..65536, at most 64 frames overlapping a sample)",
                         b, block_size[b], hop[b]);
     }
     int n_dev = 0;
@@ -390,10 +410,11 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         BandState& s = p->bands[b];
         s.n = block_size[b];
         s.hop = hop[b];
-        s.k = s.n / s.hop;
+        s.k = (s.n + s.hop - 1) / s.hop;   // frames covering one sample
         s.log2n = ilog2_exact(s.n);
-        s.kern = find_kernel(s.log2n, s.k, default_variant());
-        if (!s.kern) s.big = find_big(s.log2n, s.k);
+        // fused streaming kernel when the hop is N/2, N/4 or N/8 and N <= 8192; otherwise the unfused path
+        s.kern = (s.n % s.hop == 0 && !std::getenv("UPX_FORCE_UNFUSED")) ? find_kernel(s.log2n, s.n / s.hop, default_variant()) : nullptr;
+        if (!s.kern) s.big = find_big(s.log2n);
         if (int e = s.kern ? s.kern->prepare() : s.big->prepare()) {
             upx_plan_destroy(p);
             return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
@@ -436,6 +457,8 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         if (s.big) {
             // chunks of ~4M complex per scratch buffer (32 MB: stays in L2 / Infinity Cache)
             s.chunk_frames = (1 << 22) / s.n;
+            if (s.chunk_frames < 2 * s.k + 4) s.chunk_frames = 2 * s.k + 4;
+            s.chunk_frames += s.chunk_frames & 1;
             std::vector<upx::cf> host((size_t)s.n);
             s.big->fill_tw_n(host.data());
             HIP_TRY(hipMalloc(&s.d_tw_n, (size_t)s.n * sizeof(upx::cf)));
@@ -562,12 +585,13 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         if (j_hi > 0x7fffffffLL || m_all > 0x7fffffffLL) return fail(UPX_ERR_INVALID, "signal too long for int32 frame index");
         if (m_hi <= 0) continue;
         if (s.big) {
-            // chunked four-step path: each chunk transforms frames j0 .. j0+ch-1 (j0 odd) and emits
-            // the ch-K blocks whose K frames all lie inside it (the last frame is only a pair partner)
-            int ch = s.chunk_frames;
-            const long long want = m_hi + s.k;
-            if (want < ch) ch = (int)(want + (want & 1));
-            if (ch < s.k + 2) ch = s.k + 2;
+            // chunked unfused path: a chunk transforms frames j0 .. j0+ch-1 (j0 odd): `halo` frames that only
+            // feed the first emitted blocks, `emit` emitted blocks, one trailing pair-partner frame
+            const int halo = (s.k - 1) | 1;
+            int emit = (s.chunk_frames - halo - 1) & ~1;
+            if ((long long)emit > m_hi) emit = (int)(m_hi + (m_hi & 1));
+            if (emit < 2) emit = 2;
+            const int ch = emit + halo + 1;
             upx::BigArgs a;
             a.in = reinterpret_cast<const upx::cf*>(d_stereo);
             a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
@@ -577,13 +601,13 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             a.y = a.z + (size_t)ch * s.n;
             a.yc = a.y + (size_t)ch * s.n;
             a.t_in = (int)t_in; a.t_out = (int)t_out;
+            a.hop = s.hop; a.kf = s.k;
             a.j_lo = 0; a.j_hi = (int)j_hi; a.ch = ch;
             a.accumulate = b == 0 ? 0 : 1;
             if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
-            const int emit = ch - s.k;
             int n_chunks = 0;
             for (long long m0 = 0; m0 < m_hi; m0 += emit, ++n_chunks) {
-                a.j0 = (int)m0 - (s.k - 1);
+                a.j0 = (int)m0 - halo;
                 a.m0 = (int)m0;
                 a.m1 = (int)(m0 + emit < m_hi ? m0 + emit : m_hi);
                 s.big->chunk(a, p->stream);
