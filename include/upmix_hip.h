@@ -121,6 +121,28 @@ int upx_absmax(upx_plan* plan, const float* d_x, int64_t n, float* result);
 /* x *= scale on the device (main.py:95-97). */
 int upx_scale(upx_plan* plan, float* d_x, int64_t n, float scale);
 
+/*
+ * WAV in -> WAV out with the codec next to the kernels: the flow of main.py:43-160 for one file.
+ * Raw PCM goes up (half the bytes of float32), is decoded on the device, upmixed, peak-normalised
+ * (one global scale = peak_in / max(|Ls|,|C|,|Rs|, 1e-9), main.py:85-97) and laid out per export mode
+ * (main.py:110-157) and quantised on the device, so only final 2-channel sample data comes back.
+ *   pcm_in      interleaved samples, `channels` = 1 (duplicated to L = R, main.py:47-48) or 2
+ *   in_format / out_format   UPX_PCM16 | UPX_PCM24 (packed 3 bytes) | UPX_PCM32 | UPX_F32
+ *   mode        UPX_EXPORT_STEREO_SUM: out0 = [Ls + C/2, Rs + C/2]
+ *               UPX_EXPORT_SPLIT:      out0 = [Ls, 0], out1 = [C, C], out2 = [0, Rs]
+ *               UPX_EXPORT_AB:         out0 = [Ls + C + Rs, L + R]
+ *   out0..2     caller buffers of n_frames * 2 samples in out_format (unused ones may be NULL)
+ *   stats[3]    peak_in, overall_peak, scale_factor (the numbers main.py prints)
+ * Decoding follows python-soundfile (int / 2^(bits-1)); encoding is round-to-nearest-even of
+ * x * (2^(bits-1) - 1), clipped (libsndfile's byte-exact behaviour is not pinned).
+ */
+enum { UPX_PCM16 = 16, UPX_PCM24 = 24, UPX_PCM32 = 32, UPX_F32 = 1032 };
+enum { UPX_EXPORT_STEREO_SUM = 0, UPX_EXPORT_SPLIT = 1, UPX_EXPORT_AB = 2 };
+int upx_wav_pipeline(upx_plan* plan, const void* pcm_in, int in_format, int channels, int64_t n_frames, int mode,
+                     int out_format, void* out0, void* out1, void* out2, double* stats);
+/* Milliseconds spent in the last upx_wav_pipeline call: H2D, decode+kernels+peak+export, D2H. */
+int upx_wav_pipeline_times_ms(upx_plan* plan, float* ms3);
+
 /* ---- multi-GPU seam exchange over RCCL (one process per GPU) ------------ */
 #define UPX_UNIQUE_ID_BYTES 128
 /* Rank 0 creates the id and shares the 128 bytes with the other ranks out of band. */

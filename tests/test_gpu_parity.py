@@ -318,3 +318,50 @@ def test_rccl_single_rank_communicator(ux, orc):
     for p in d:
         plan.free(p)
     plan.close()
+
+
+def test_wav_pipeline_device_codec_and_cli(ux, orc, tmp_path):
+    """WAV bytes in -> exported WAV out with codec, peak scale and layouts on the GPU."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from upmix_amd import wav, export, _lib, cli
+    z = load_golden("f7_main.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "f7_main.json")))
+    x = z["x"]                                     # float32 [T,2]; main.py itself produced the golden outputs from it
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 48000, verbose=False)
+    plan = ux.DevicePlan(bands)
+    for mode in ("stereo_sum", "split", "AB"):
+        payloads, stats = plan.wav_pipeline(x, _lib.F32, 2, len(x), mode, _lib.F32)
+        assert f"Applying scale_factor = {stats['scale_factor']:.4f}" in meta[mode]["log_tail"]
+        names = export.export_file_names("eyes", mode, bands, 0.75)
+        for key, raw in payloads.items():
+            got = raw.view(np.float32).reshape(-1, 2)
+            want = z[f"{mode}:{os.path.join('out', names[key])}"]
+            assert rms(got.astype(np.float64) - want) <= 3e-5      # 1e-5 x scale_factor 2.8
+    # integer PCM: decode and quantise on the device == the host codec
+    rng = np.random.default_rng(3)
+    pcm = (rng.standard_normal((50000, 2)) * 3000).astype(np.int16)
+    payloads, stats = plan.wav_pipeline(pcm, _lib.PCM16, 2, len(pcm), "stereo_sum", _lib.PCM16)
+    xf = pcm.astype(np.float64) / 32768.0
+    c, l, r = plan.process(xf.astype(np.float32))
+    scale, _ = export.scale_to_input_peak(c, l, r, export.input_peak(xf))
+    assert abs(scale - stats["scale_factor"]) <= 1e-6 * scale
+    ref = export.export_arrays("stereo_sum", c, l, r)["Sum"]
+    q = np.clip(np.rint(ref.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    got = payloads["Sum"].view(np.int16).reshape(-1, 2)
+    assert np.max(np.abs(got.astype(np.int32) - q)) <= 1           # identical up to ties of float rounding
+    plan.close()
+    # the CLI end to end: mono 24-bit file in, three split files out
+    os.makedirs(tmp_path / "in")
+    mono = rng.uniform(-0.5, 0.5, 30000)
+    wav.write(str(tmp_path / "in" / "tone.wav"), mono, 44100, "PCM_24")
+    written = cli.run("tone.wav", "split", str(tmp_path / "in"), str(tmp_path / "out"), max_stft=4096)
+    assert sorted(written) == ["C", "Ls", "Rs"]
+    c_wav, sr = wav.read(written["C"])
+    ls_wav, _ = wav.read(written["Ls"])
+    assert sr == 44100 and c_wav.shape == (30000, 2) and np.array_equal(c_wav[:, 0], c_wav[:, 1])
+    assert not ls_wav[:, 1].any() and np.max(np.abs(ls_wav[:, 0])) < 1e-3     # mono input: everything is centre
+    host = cli.run("tone.wav", "split", str(tmp_path / "in"), str(tmp_path / "out_host"), max_stft=4096, host_export=True)
+    c_host, _ = wav.read(host["C"])
+    assert np.max(np.abs(c_host - c_wav)) <= 2.0 / 32768

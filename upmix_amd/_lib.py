@@ -22,6 +22,8 @@ UPX_ERR_NO_DEVICE = -4
 UPX_ERR_RCCL = -5
 UPX_ERR_NOMEM = -6
 UNIQUE_ID_BYTES = 128
+PCM16, PCM24, PCM32, F32 = 16, 24, 32, 1032
+EXPORT_STEREO_SUM, EXPORT_SPLIT, EXPORT_AB = 0, 1, 2
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -51,6 +53,9 @@ SIGNATURES = {
     "upx_plan_band_group": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p]),
     "upx_absmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, f32p]),
     "upx_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
+    "upx_wav_pipeline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "upx_wav_pipeline_times_ms": (C.c_int, [C.c_void_p, f32p]),
     "upx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "upx_comm_create": (C.c_int, [vpp, C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "upx_comm_destroy": (None, [C.c_void_p]),

@@ -4,8 +4,9 @@ WAV in -> Ls/C/Rs WAV out on an MI355X: the flow of python-prototype/main.py
 (load :43, mono->stereo :47-48, peak :53-55, chain_bands :67-73, extract :78-80,
 scale :85-97, export :110-160) with the constants the reference asks the user to
 edit exposed as arguments.  Defaults reproduce main.py (eyes.wav, stereo_sum,
-edges 0/30/120/480/1920/7680, overlap 0.75, Blackman-Harris, raised cosine)
-except --max-stft, which defaults to the largest size the kernels cover.
+edges 0/30/120/480/1920/7680, overlap 0.75, Blackman-Harris, raised cosine, STFT up to 65536).
+By default the WAV codec, the peak normalisation and the export layouts run on the GPU too
+(upx_wav_pipeline); --host-export keeps them in NumPy.
 
     python -m upmix_amd.cli eyes.wav --export-mode split
 """
@@ -32,13 +33,25 @@ _WRITE_NOTES = {
 
 def run(in_filename: str = "eyes.wav", export_mode: str = "stereo_sum", in_dir: str = "in", out_dir: str = "out",
         band_edges=(0, 30, 120, 480, 1920, 7680), overlap: float = 0.75, window: str = "blackman_harris",
-        xover_mode: str = "raised_cosine", max_stft: int = 8192, threshold_factor: float = 32,
-        xo_fraction: float = 0.25, device: int = 0, subtype: str = "PCM_16", reader=wav.read, writer=wav.write):
+        xover_mode: str = "raised_cosine", max_stft: int = 65536, threshold_factor: float = 32,
+        xo_fraction: float = 0.25, device: int = 0, subtype: str = "PCM_16", host_export: bool = False,
+        reader=wav.read, writer=wav.write):
     """One file through the path; returns {name: path} of the files written."""
     os.makedirs(out_dir, exist_ok=True)
     in_path = os.path.join(in_dir, in_filename)
     if not os.path.isfile(in_path):
         raise FileNotFoundError(f"File not found: {in_path}")
+    base_in_name = os.path.splitext(in_filename)[0]
+    custom_io = reader is not wav.read or writer is not wav.write
+    if not host_export and not custom_io and export_mode in export.EXPORT_MODES:
+        try:
+            raw, kind, channels, sr, n_frames = wav.read_raw(in_path)
+        except ValueError:
+            raw = None
+        if raw is not None and channels in (1, 2) and 0 < n_frames < (1 << 29):
+            return _run_device_codec(raw, kind, channels, sr, n_frames, in_path, base_in_name, export_mode, out_dir,
+                                     band_edges, overlap, window, xover_mode, max_stft, threshold_factor, xo_fraction,
+                                     device, subtype)
     wave, sr = reader(in_path)
     print(f"Loaded '{in_path}', sr={sr}, shape={wave.shape}")
     if wave.ndim == 1:
@@ -57,7 +70,6 @@ def run(in_filename: str = "eyes.wav", export_mode: str = "stereo_sum", in_dir: 
     print(f"Original peak = {peak_in:.4f}, L/C/R peak = {overall_peak:.4f}")
     print(f"Applying scale_factor = {scale_factor:.4f}")
 
-    base_in_name = os.path.splitext(in_filename)[0]
     arrays = export.export_arrays(export_mode, final_center, final_left, final_right, L, R)
     names = export.export_file_names(base_in_name, export_mode, band_extractors, overlap)
     written = {}
@@ -76,6 +88,36 @@ def run(in_filename: str = "eyes.wav", export_mode: str = "stereo_sum", in_dir: 
     return written
 
 
+_SUBTYPE_KIND = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32, "FLOAT": 1032}
+
+
+def _run_device_codec(raw, kind, channels, sr, n_frames, in_path, base_in_name, export_mode, out_dir, band_edges,
+                      overlap, window, xover_mode, max_stft, threshold_factor, xo_fraction, device, subtype):
+    """Same flow with decode, peak scale, export layout and quantisation on the GPU (upx_wav_pipeline)."""
+    from .extractor import DevicePlan
+    print(f"Loaded '{in_path}', sr={sr}, shape={(n_frames, channels) if channels > 1 else (n_frames,)}")
+    band_extractors = chain_bands(list(band_edges), overlap, WINDOW_FUNCS[window], sr, xover_mode,
+                                  max_block_size=max_stft, threshold_factor=threshold_factor,
+                                  xo_fraction=xo_fraction, device=device)
+    plan = DevicePlan(band_extractors, device)
+    try:
+        payloads, stats = plan.wav_pipeline(raw, kind, channels, n_frames, export_mode, _SUBTYPE_KIND[subtype])
+    finally:
+        plan.close()
+    print(f"Original peak = {stats['peak_in']:.4f}, L/C/R peak = {stats['overall_peak']:.4f}")
+    print(f"Applying scale_factor = {stats['scale_factor']:.4f}")
+    names = export.export_file_names(base_in_name, export_mode, band_extractors, overlap)
+    written = {}
+    for key in ("AB", "Ls", "C", "Rs", "Sum"):
+        if key in payloads:
+            path = os.path.join(out_dir, names[key])
+            wav.write_raw(path, payloads[key], sr, _SUBTYPE_KIND[subtype], 2)
+            print(_WRITE_NOTES[key].format(path=path))
+            written[key] = path
+    print("Done.")
+    return written
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="upmix_amd.cli", description=__doc__.split("\n\n")[0])
     ap.add_argument("in_filename", nargs="?", default="eyes.wav", help="WAV name inside --in-dir")
@@ -86,14 +128,15 @@ def main(argv=None) -> int:
     ap.add_argument("--overlap", type=float, default=0.75)
     ap.add_argument("--window", default="blackman_harris", choices=sorted(WINDOW_FUNCS))
     ap.add_argument("--xover-mode", default="raised_cosine")
-    ap.add_argument("--max-stft", type=int, default=8192, help="max STFT size (reference: 65536)")
+    ap.add_argument("--max-stft", type=int, default=65536, help="max STFT size (reference: 65536; BASELINE configs use 8192)")
+    ap.add_argument("--host-export", action="store_true", help="decode / scale / export with NumPy on the host instead of on the GPU")
     ap.add_argument("--threshold-factor", type=float, default=32)
     ap.add_argument("--xo-fraction", type=float, default=0.25)
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--subtype", default="PCM_16", choices=["PCM_16", "PCM_24", "PCM_32", "FLOAT"])
     a = ap.parse_args(argv)
     run(a.in_filename, a.export_mode, a.in_dir, a.out_dir, [float(v) for v in a.band_edges.split(",")], a.overlap,
-        a.window, a.xover_mode, a.max_stft, a.threshold_factor, a.xo_fraction, a.device, a.subtype)
+        a.window, a.xover_mode, a.max_stft, a.threshold_factor, a.xo_fraction, a.device, a.subtype, a.host_export)
     return 0
 
 

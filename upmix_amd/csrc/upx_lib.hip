@@ -89,6 +89,54 @@ __global__ void upx_scale_kernel(float* x, long long n, float s) {
         x[i] *= s;
 }
 
+// ---- device-side WAV codec + export layouts (main.py:43-55, 85-97, 110-157) -------------------
+__device__ __forceinline__ float upx_decode_sample(const unsigned char* p, long long i, int fmt) {
+    if (fmt == UPX_PCM16) return (float)reinterpret_cast<const short*>(p)[i] * (1.0f / 32768.0f);
+    if (fmt == UPX_PCM32) return (float)((double)reinterpret_cast<const int*>(p)[i] * (1.0 / 2147483648.0));
+    if (fmt == UPX_F32) return reinterpret_cast<const float*>(p)[i];
+    const unsigned char* b = p + 3 * i;   // 24-bit little endian, sign extended
+    int v = (int)b[0] | ((int)b[1] << 8) | ((int)(signed char)b[2] << 16);
+    return (float)v * (1.0f / 8388608.0f);
+}
+__global__ void upx_decode_kernel(const unsigned char* pcm, int fmt, int channels, long long n, float* stereo) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float l = upx_decode_sample(pcm, channels == 2 ? 2 * i : i, fmt);
+        const float r = channels == 2 ? upx_decode_sample(pcm, 2 * i + 1, fmt) : l;
+        stereo[2 * i] = l;
+        stereo[2 * i + 1] = r;
+    }
+}
+__device__ __forceinline__ void upx_encode_sample(unsigned char* p, long long i, int fmt, float x) {
+    if (fmt == UPX_F32) { reinterpret_cast<float*>(p)[i] = x; return; }
+    const int bits = fmt;
+    const double full = (double)((1ll << (bits - 1)) - 1);
+    double q = rint((double)x * full);
+    q = q > full ? full : (q < -full - 1.0 ? -full - 1.0 : q);
+    const long long v = (long long)q;
+    if (fmt == UPX_PCM16) reinterpret_cast<short*>(p)[i] = (short)v;
+    else if (fmt == UPX_PCM32) reinterpret_cast<int*>(p)[i] = (int)v;
+    else { unsigned char* b = p + 3 * i; b[0] = (unsigned char)(v & 0xff); b[1] = (unsigned char)((v >> 8) & 0xff); b[2] = (unsigned char)((v >> 16) & 0xff); }
+}
+// planes are scaled like `final_x *= scale_factor` (float32 array times a float64 scalar: product in double,
+// rounded to float32), then combined in float32 exactly as main.py does
+__global__ void upx_export_kernel(const float* c, const float* l, const float* r, const float* stereo, long long n,
+                                  double scale, int mode, int fmt, unsigned char* o0, unsigned char* o1, unsigned char* o2) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float fc = (float)((double)c[i] * scale), fl = (float)((double)l[i] * scale), fr = (float)((double)r[i] * scale);
+        if (mode == UPX_EXPORT_STEREO_SUM) {
+            upx_encode_sample(o0, 2 * i, fmt, fl + 0.5f * fc);
+            upx_encode_sample(o0, 2 * i + 1, fmt, fr + 0.5f * fc);
+        } else if (mode == UPX_EXPORT_SPLIT) {
+            upx_encode_sample(o0, 2 * i, fmt, fl); upx_encode_sample(o0, 2 * i + 1, fmt, 0.f);
+            upx_encode_sample(o1, 2 * i, fmt, fc); upx_encode_sample(o1, 2 * i + 1, fmt, fc);
+            upx_encode_sample(o2, 2 * i, fmt, 0.f); upx_encode_sample(o2, 2 * i + 1, fmt, fr);
+        } else {
+            upx_encode_sample(o0, 2 * i, fmt, (fl + fc) + fr);
+            upx_encode_sample(o0, 2 * i + 1, fmt, stereo[2 * i] + stereo[2 * i + 1]);
+        }
+    }
+}
+
 // seam[row][plane][spill] <- planes[own_len + i]; other rows zero (done by memset)
 __global__ void upx_seam_pack_kernel(float* seam_row, const float* c, const float* l, const float* r,
                                      long long own_len, long long spill) {
@@ -292,6 +340,7 @@ struct upx_plan {
     bool timing = false;
     bool timed_once = false;
     unsigned int* d_scalar = nullptr;
+    float pipe_ms[3] = {0.f, 0.f, 0.f};
     upx::cf* d_scratch = nullptr;   // z | y | yc of the big path (shared by all big bands)
     size_t scratch_cf = 0;
 };
@@ -736,6 +785,88 @@ int upx_scale(upx_plan* p, float* d_x, int64_t n, float scale) {
     HIP_TRY(hipSetDevice(p->device));
     if (n > 0) hipLaunchKernelGGL(upx_scale_kernel, dim3(grid_for(n)), dim3(256), 0, p->stream, d_x, (long long)n, scale);
     HIP_TRY(hipGetLastError());
+    return UPX_OK;
+}
+
+int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channels, int64_t n, int mode, int out_format,
+                     void* out0, void* out1, void* out2, double* stats) {
+    auto bytes_of = [](int fmt) { return fmt == UPX_F32 ? 4 : fmt / 8; };
+    if (!p || !pcm_in || n < 0 || (channels != 1 && channels != 2) || !stats)
+        return fail(UPX_ERR_INVALID, "upx_wav_pipeline: bad argument");
+    if ((in_format != UPX_PCM16 && in_format != UPX_PCM24 && in_format != UPX_PCM32 && in_format != UPX_F32) ||
+        (out_format != UPX_PCM16 && out_format != UPX_PCM24 && out_format != UPX_PCM32 && out_format != UPX_F32))
+        return fail(UPX_ERR_INVALID, "upx_wav_pipeline: unknown sample format");
+    if (mode != UPX_EXPORT_STEREO_SUM && mode != UPX_EXPORT_SPLIT && mode != UPX_EXPORT_AB)
+        return fail(UPX_ERR_INVALID, "upx_wav_pipeline: unknown export mode");
+    const int n_out = mode == UPX_EXPORT_SPLIT ? 3 : 1;
+    void* outs[3] = {out0, out1, out2};
+    for (int i = 0; i < n_out; ++i)
+        if (!outs[i]) return fail(UPX_ERR_INVALID, "upx_wav_pipeline: output buffer %d is NULL", i);
+    stats[0] = 1e-9; stats[1] = 1e-9; stats[2] = 1.0;
+    if (n == 0) return UPX_OK;
+    if (n >= (1LL << 29)) return fail(UPX_ERR_INVALID, "upx_wav_pipeline: at most 2^29-1 frames per call");
+    HIP_TRY(hipSetDevice(p->device));
+    const size_t in_bytes = (size_t)n * channels * bytes_of(in_format);
+    const size_t out_bytes = (size_t)n * 2 * bytes_of(out_format);
+    unsigned char *d_pcm = nullptr, *d_o[3] = {nullptr, nullptr, nullptr};
+    float *d_st = nullptr, *d_pl = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = UPX_OK;
+    auto cleanup = [&]() {
+        if (d_pcm) (void)hipFree(d_pcm);
+        if (d_st) (void)hipFree(d_st);
+        if (d_pl) (void)hipFree(d_pl);
+        for (auto* q : d_o) if (q) (void)hipFree(q);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    };
+#define PIPE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(UPX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    PIPE_TRY(hipMalloc(&d_pcm, in_bytes));
+    PIPE_TRY(hipMalloc(&d_st, (size_t)n * 2 * sizeof(float)));
+    PIPE_TRY(hipMalloc(&d_pl, (size_t)n * 3 * sizeof(float)));
+    for (int i = 0; i < n_out; ++i) PIPE_TRY(hipMalloc(&d_o[i], out_bytes));
+    for (auto& e : ev) PIPE_TRY(hipEventCreate(&e));
+    // pinning the caller's buffers lets the copies run at PCIe rate; ignore failures (already pinned / not allowed)
+    const bool pin_in = hipHostRegister(const_cast<void*>(pcm_in), in_bytes, hipHostRegisterDefault) == hipSuccess;
+    bool pin_out[3] = {false, false, false};
+    for (int i = 0; i < n_out; ++i) pin_out[i] = hipHostRegister(outs[i], out_bytes, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    do {
+        hipStream_t st = p->stream;
+        if (hipEventRecord(ev[0], st) != hipSuccess) { rc = fail(UPX_ERR_HIP, "event"); break; }
+        if (hipMemcpyAsync(d_pcm, pcm_in, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(UPX_ERR_HIP, "H2D copy failed"); break; }
+        (void)hipEventRecord(ev[1], st);
+        hipLaunchKernelGGL(upx_decode_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_pcm, in_format, channels, (long long)n, d_st);
+        rc = upx_process_device(p, d_st, n, n, d_pl, d_pl + n, d_pl + 2 * n, n);
+        if (rc) break;
+        float peak_in = 0.f, peak_out = 0.f;
+        rc = upx_absmax(p, d_st, 2 * n, &peak_in);
+        if (!rc) rc = upx_absmax(p, d_pl, 3 * n, &peak_out);
+        if (rc) break;
+        const double pin = peak_in <= 0.f ? 1e-9 : (double)peak_in;                 // main.py:53-55
+        const double overall = (double)peak_out > 1e-9 ? (double)peak_out : 1e-9;   // main.py:88
+        const double scale = pin / overall;                                         // main.py:90
+        stats[0] = pin; stats[1] = overall; stats[2] = scale;
+        hipLaunchKernelGGL(upx_export_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_pl, d_pl + n, d_pl + 2 * n, d_st,
+                           (long long)n, scale, mode, out_format, d_o[0], d_o[1], d_o[2]);
+        (void)hipEventRecord(ev[2], st);
+        bool bad = false;
+        for (int i = 0; i < n_out; ++i)
+            bad |= hipMemcpyAsync(outs[i], d_o[i], out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess;
+        (void)hipEventRecord(ev[3], st);
+        hipError_t se = hipStreamSynchronize(st);
+        if (bad || se != hipSuccess) { rc = fail(UPX_ERR_HIP, "kernel or D2H copy failed: %s", hipGetErrorString(se)); break; }
+        for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&p->pipe_ms[i], ev[i], ev[i + 1]);
+    } while (0);
+    if (pin_in) (void)hipHostUnregister(const_cast<void*>(pcm_in));
+    for (int i = 0; i < n_out; ++i) if (pin_out[i]) (void)hipHostUnregister(outs[i]);
+    cleanup();
+#undef PIPE_TRY
+    return rc;
+}
+
+int upx_wav_pipeline_times_ms(upx_plan* p, float* ms3) {
+    if (!p || !ms3) return fail(UPX_ERR_INVALID, "upx_wav_pipeline_times_ms: bad argument");
+    for (int i = 0; i < 3; ++i) ms3[i] = p->pipe_ms[i];
     return UPX_OK;
 }
 

@@ -128,6 +128,33 @@ class DevicePlan:
     def scale(self, ptr: int, n: int, factor: float) -> None:
         _lib.check(self._lib.upx_scale(self.handle, C.c_void_p(ptr), int(n), float(factor)))
 
+    def wav_pipeline(self, pcm: np.ndarray, in_format: int, channels: int, n_frames: int, mode: str,
+                     out_format: int = 16):
+        """
+        Raw PCM in -> final 2-channel sample data out, everything between on the device
+        (decode, all bands, global peak scale, export layout, quantisation).  Returns
+        ({"Sum"|"AB"|"Ls","C","Rs": uint8 payload}, {"peak_in", "overall_peak", "scale_factor"}).
+        main.py:43-160; `mode` in ("stereo_sum", "split", "AB").
+        """
+        modes = {"stereo_sum": (_lib.EXPORT_STEREO_SUM, ("Sum",)), "split": (_lib.EXPORT_SPLIT, ("Ls", "C", "Rs")),
+                 "AB": (_lib.EXPORT_AB, ("AB",))}
+        if mode not in modes:
+            raise ValueError(f"unknown export mode {mode!r}")
+        code, names = modes[mode]
+        width = 4 if out_format == _lib.F32 else out_format // 8
+        src = np.ascontiguousarray(pcm).view(np.uint8)
+        outs = [np.empty(n_frames * 2 * width, dtype=np.uint8) for _ in names]
+        ptrs = [o.ctypes.data_as(C.c_void_p) for o in outs] + [None] * (3 - len(outs))
+        stats = (C.c_double * 3)()
+        _lib.check(self._lib.upx_wav_pipeline(self.handle, src.ctypes.data_as(C.c_void_p), int(in_format), int(channels),
+                                              int(n_frames), code, int(out_format), ptrs[0], ptrs[1], ptrs[2], stats))
+        return dict(zip(names, outs)), {"peak_in": stats[0], "overall_peak": stats[1], "scale_factor": stats[2]}
+
+    def wav_pipeline_times_ms(self):
+        ms = np.zeros(3, dtype=np.float32)
+        _lib.check(self._lib.upx_wav_pipeline_times_ms(self.handle, _f32p(ms)))
+        return {"h2d": float(ms[0]), "device": float(ms[1]), "d2h": float(ms[2])}
+
     def seam_add_local(self, prev: Sequence[int], prev_own_len: int, nxt: Sequence[int], spill: int) -> None:
         _lib.check(self._lib.upx_seam_add_local(self.handle, *(C.c_void_p(p) for p in prev), int(prev_own_len),
                                                 *(C.c_void_p(p) for p in nxt), int(spill)))

@@ -92,3 +92,51 @@ def write(path: str, data: np.ndarray, samplerate: int, subtype: str = "PCM_16")
         fh.write(b"data" + struct.pack("<I", len(payload)) + payload)
         if len(payload) & 1:
             fh.write(b"\x00")
+
+
+# ---- raw access for the device-side codec (upx_wav_pipeline) ---------------------------------------
+def read_raw(path: str):
+    """-> (samples uint8[...] raw little-endian payload, fmt code, channels, sample_rate, n_frames).
+    fmt: 16 / 24 / 32 (integer PCM) or 1032 (float32); anything else raises ValueError."""
+    with open(path, "rb") as fh:
+        blob = fh.read()
+    if len(blob) < 12 or blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError(f"{path}: not a RIFF/WAVE file")
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(blob):
+        tag, size = blob[pos:pos + 4], struct.unpack("<I", blob[pos + 4:pos + 8])[0]
+        if tag == b"fmt ":
+            fmt = blob[pos + 8:pos + 8 + size]
+        elif tag == b"data":
+            data = (pos + 8, min(size, len(blob) - pos - 8))
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError(f"{path}: missing fmt or data chunk")
+    code, channels, rate, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if code == _EXT and len(fmt) >= 26:
+        code = struct.unpack("<H", fmt[24:26])[0]
+    if code == _PCM and bits in (16, 24, 32):
+        kind = bits
+    elif code == _FLOAT and bits == 32:
+        kind = 1032
+    else:
+        raise ValueError(f"{path}: encoding (format {code}, {bits} bits) is not handled by the device codec")
+    width = bits // 8
+    n_frames = data[1] // (width * channels)
+    raw = np.frombuffer(blob, dtype=np.uint8, count=n_frames * width * channels, offset=data[0])
+    return raw, kind, int(channels), int(rate), int(n_frames)
+
+
+def write_raw(path: str, payload: np.ndarray, samplerate: int, kind: int, channels: int = 2) -> None:
+    """payload: uint8 little-endian interleaved samples in `kind` (16/24/32 PCM or 1032 float32)."""
+    bits = 32 if kind == 1032 else kind
+    code = _FLOAT if kind == 1032 else _PCM
+    block = channels * bits // 8
+    body = np.ascontiguousarray(payload).view(np.uint8).tobytes()
+    fmt = struct.pack("<HHIIHH", code, channels, int(samplerate), int(samplerate) * block, block, bits)
+    with open(path, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + len(body) + (len(body) & 1)) + b"WAVE")
+        fh.write(b"fmt " + struct.pack("<I", len(fmt)) + fmt)
+        fh.write(b"data" + struct.pack("<I", len(body)) + body)
+        if len(body) & 1:
+            fh.write(b"\x00")
