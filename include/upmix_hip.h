@@ -156,6 +156,10 @@ void upx_comm_destroy(upx_comm* comm);
  * own_len == 0 ranks are not supported.
  */
 int upx_comm_seam_exchange(upx_comm* comm, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill);
+/* Test hook: run the same pack -> ncclAllReduce -> add sequence with a seam of n_rows rows, packing this rank's
+   spill into row my_row and adding that same row back onto its own head (any communicator size, e.g. 1 rank). */
+int upx_comm_seam_selftest(upx_comm* comm, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill,
+                           int n_rows, int my_row);
 /* Same seam arithmetic between two shards on ONE device (no RCCL): adds the
    spill of the `prev` planes onto the head of the `next` planes. */
 int upx_seam_add_local(upx_plan* plan, const float* prev_c, const float* prev_l, const float* prev_r,

@@ -94,6 +94,29 @@ def default_plan_timing(seconds=600, reps=3):
         print(f"default plan prefix {name}: rms err {rms(g[:pre-65536].astype(np.float64) - r[:pre-65536]):.2e}")
 
 
+def e2e_timing(seconds=600, reps=4):
+    """PCIe-inclusive rates: host float32 planes (upx_process) and the PCM16 WAV pipeline."""
+    from upmix_amd import _lib
+    sr = 48000
+    total = sr * seconds
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, sr, max_block_size=8192,
+                           verbose=False)
+    plan = ux.DevicePlan(bands)
+    x = orc.synthetic_stereo(total, 2)
+    for r in range(reps):
+        t0 = time.perf_counter()
+        plan.process(x)
+        dt = time.perf_counter() - t0
+        print(f"upx_process (host f32 in, 3 f32 planes out) rep {r}: {dt*1e3:.1f} ms -> {total/dt/1e6:.1f} Msamples/s", flush=True)
+    pcm = np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.int16)
+    for r in range(reps):
+        t0 = time.perf_counter()
+        plan.wav_pipeline(pcm, _lib.PCM16, 2, total, "stereo_sum", _lib.PCM16)
+        dt = time.perf_counter() - t0
+        print(f"upx_wav_pipeline (PCM16 in, PCM16 stereo_sum out) rep {r}: {dt*1e3:.1f} ms -> {total/dt/1e6:.1f} Msamples/s "
+              f"{plan.wav_pipeline_times_ms()}", flush=True)
+
+
 if __name__ == "__main__":
     print("variant", os.environ.get("UPX_KERNEL_VARIANT", "0"))
     if "parity" in sys.argv:
@@ -102,3 +125,5 @@ if __name__ == "__main__":
         c3_timing()
     if "default" in sys.argv:
         default_plan_timing()
+    if "e2e" in sys.argv:
+        e2e_timing()

@@ -306,14 +306,26 @@ def test_device_helpers_absmax_scale(ux, orc):
 
 
 def test_rccl_single_rank_communicator(ux, orc):
-    """dlopen of RCCL, unique id, ncclCommInitRank and the seam call with one rank (no-op exchange)."""
+    """dlopen of RCCL, unique id, ncclCommInitRank, and the seam pack -> ncclAllReduce -> add kernels on real sizes."""
     from upmix_amd import sharding
     bands = gpu_chain(ux, [0, 300, 3000], 48000, 1024, 32)
     plan = ux.DevicePlan(bands)
     seam = sharding.RcclSeam(plan, 0, 1, broadcast=lambda b: b)
-    d = [plan.alloc(4096 * 4) for _ in range(3)]
-    seam.exchange(d, 2048, 768)
+    own, spill = 50000, 6144
+    rng = np.random.default_rng(5)
+    host = [rng.standard_normal(own + spill).astype(np.float32) for _ in range(3)]
+    d = [plan.alloc((own + spill) * 4) for _ in range(3)]
+    for p, h in zip(d, host):
+        plan.h2d(p, h)
+    seam.exchange(d, own, spill)          # one rank: nothing to exchange
+    seam.selftest(d, own, spill, 8, 5)    # 8-row seam, my spill in row 5, all-reduce, add row 5 onto my head
     plan.sync()
+    for p, h in zip(d, host):
+        got = np.empty_like(h)
+        plan.d2h(got, p)
+        want = h.copy()
+        want[:spill] += h[own:own + spill]
+        assert np.array_equal(got, want)
     seam.close()
     for p in d:
         plan.free(p)

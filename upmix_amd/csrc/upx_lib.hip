@@ -909,12 +909,13 @@ void upx_comm_destroy(upx_comm* c) {
     delete c;
 }
 
-int upx_comm_seam_exchange(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill) {
-    if (!c || !d_c || !d_l || !d_r || own_len <= 0 || spill < 0) return fail(UPX_ERR_INVALID, "upx_comm_seam_exchange: bad argument");
-    if (spill == 0 || c->n_ranks == 1) return UPX_OK;
+namespace {
+// pack my spill into row `my_row` of seam[n_rows][3][spill], all-reduce, add row `add_row` onto my head
+int seam_exchange_impl(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill, int n_rows,
+                       int my_row, bool pack, int add_row) {
     upx_plan* p = c->plan;
     HIP_TRY(hipSetDevice(p->device));
-    const long long row = 3 * (long long)spill, total = row * c->n_ranks;
+    const long long row = 3 * (long long)spill, total = row * n_rows;
     if (c->seam_floats < total) {
         if (c->d_seam) HIP_TRY(hipFree(c->d_seam));
         c->d_seam = nullptr;
@@ -922,17 +923,33 @@ int upx_comm_seam_exchange(upx_comm* c, float* d_c, float* d_l, float* d_r, int6
         c->seam_floats = total;
     }
     HIP_TRY(hipMemsetAsync(c->d_seam, 0, (size_t)total * sizeof(float), p->stream));
-    if (c->rank + 1 < c->n_ranks)   // the last rank's spill lies beyond the signal
+    if (pack)
         hipLaunchKernelGGL(upx_seam_pack_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream,
-                           c->d_seam + row * c->rank, d_c, d_l, d_r, (long long)own_len, (long long)spill);
+                           c->d_seam + row * my_row, d_c, d_l, d_r, (long long)own_len, (long long)spill);
     NCCL_TRY(g_rccl.AllReduce(c->d_seam, c->d_seam, (size_t)total, ncclFloat32, ncclSum, c->comm, p->stream));
-    if (c->rank > 0) {
-        const float* prev = c->d_seam + row * (c->rank - 1);
+    if (add_row >= 0) {
+        const float* prev = c->d_seam + row * add_row;
         hipLaunchKernelGGL(upx_seam_add_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream, d_c, d_l, d_r, prev,
                            prev + spill, prev + 2 * spill, (long long)spill);
     }
     HIP_TRY(hipGetLastError());
     return UPX_OK;
+}
+}   // namespace
+
+int upx_comm_seam_exchange(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill) {
+    if (!c || !d_c || !d_l || !d_r || own_len <= 0 || spill < 0) return fail(UPX_ERR_INVALID, "upx_comm_seam_exchange: bad argument");
+    if (spill == 0 || c->n_ranks == 1) return UPX_OK;
+    // the last rank's spill lies beyond the signal; rank 0 has no predecessor
+    return seam_exchange_impl(c, d_c, d_l, d_r, own_len, spill, c->n_ranks, c->rank, c->rank + 1 < c->n_ranks,
+                              c->rank > 0 ? c->rank - 1 : -1);
+}
+
+int upx_comm_seam_selftest(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill, int n_rows,
+                           int my_row) {
+    if (!c || !d_c || !d_l || !d_r || own_len <= 0 || spill <= 0 || n_rows < 1 || my_row < 0 || my_row >= n_rows)
+        return fail(UPX_ERR_INVALID, "upx_comm_seam_selftest: bad argument");
+    return seam_exchange_impl(c, d_c, d_l, d_r, own_len, spill, n_rows, my_row, true, my_row);
 }
 
 int upx_seam_add_local(upx_plan* p, const float* pc, const float* pl, const float* pr, int64_t prev_own_len,

@@ -159,6 +159,11 @@ class RcclSeam:
         _lib.check(self._lib.upx_comm_seam_exchange(self.handle, *(C.c_void_p(p) for p in d_planes),
                                                     int(own_len), int(spill)))
 
+    def selftest(self, d_planes: Sequence[int], own_len: int, spill: int, n_rows: int, my_row: int) -> None:
+        """pack -> ncclAllReduce -> add with an n_rows seam on this communicator (see upx_comm_seam_selftest)."""
+        _lib.check(self._lib.upx_comm_seam_selftest(self.handle, *(C.c_void_p(p) for p in d_planes), int(own_len),
+                                                    int(spill), int(n_rows), int(my_row)))
+
     def close(self) -> None:
         if self.handle:
             self._lib.upx_comm_destroy(self.handle)
