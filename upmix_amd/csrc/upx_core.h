@@ -73,6 +73,11 @@ UPX_HD const UPX_GLOBAL T* opaque(const T* p) {
     return p;
 #endif
 }
+// LDS read of one complex.  (Tried: forcing single ds_read_b64 with volatile address_space(3) loads,
+// because the backend pairs neighbours into ds_read2_b64 at half the bytes per clock; the ordering
+// constraints of volatile cost more than the pairing - 3.9 ms vs 2.75 ms for C3 - so plain loads stay.)
+UPX_HD cf lds_load(const cf* p) { return *p; }
+
 // Stops the instruction scheduler from interleaving independent unrolled
 // iterations across this point (it otherwise trades ~130 extra VGPRs for ILP).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -316,7 +321,7 @@ struct Stream {
             if (NS > 1) {
                 const cf* row = tw + OFF + ((lane + q * LANES) & (NS - 1));
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[r] = cmul(v[r], row[(r - 1) * NS]);
+                for (int r = 1; r < R; ++r) v[r] = cmul(v[r], lds_load(row + (r - 1) * NS));
             }
             Dft<R>::run(v);
 #pragma unroll
@@ -340,7 +345,7 @@ struct Stream {
     static UPX_HD void read_all(Thread& th, const cf* lds, int lane) {
         const cf* b = lds + padp<P>(lane);
 #pragma unroll
-        for (int s = 0; s < P; ++s) th.x[s] = b[s * C::SPITCH];
+        for (int s = 0; s < P; ++s) th.x[s] = lds_load(b + s * C::SPITCH);
     }
 
     // passes PI..n-2:  [read, transform] | [scatter] |   ('|' = barrier)
@@ -605,7 +610,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         for (int s = 0; s < H; ++s) {
             const bool dc = s == 0 && lane == 0;   // k == 0
             const cf za = th.x[s];
-            const cf zp = zpart[(H - 1 - s) * SP];   // for k == 0 this is index N (spare row), unused
+            const cf zp = lds_load(zpart + (H - 1 - s) * SP);   // for k == 0 this is index N (spare row), unused
             const cf zb = dc ? za : zp;              // DC pairs with itself
             const cf l0 = mk(za.x + zb.x, za.y - zb.y);   // Z[k] + conj Z[N-k]        (x gain/2 = L)
             const cf r0 = mk(za.y + zb.y, zb.x - za.x);   // (Z[k] - conj Z[N-k]) / i  (x gain/2 = R)
@@ -656,7 +661,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const int lane = tid % LANES;
         const cf* b = lds_all + (tid / LANES) * C::PITCH + padp<P>(lane);
 #pragma unroll
-        for (int s = H; s < P; ++s) th.x[s] = b[(s - H) * SP];
+        for (int s = H; s < P; ++s) th.x[s] = lds_load(b + (s - H) * SP);
         S::template pass_compute<0>(th, tw, lane);
     };
     auto scatter0 = [&](int tid, Thread& th) {
