@@ -19,6 +19,12 @@ struct SeqExec {
     void each(F&& f) {
         for (size_t t = 0; t < st.size(); ++t) f((int)t, st[t]);
     }
+    // f reads, g scatters: all reads happen before any write (barrier, or in-order LDS issue of one wave)
+    template <class F, class G>
+    void each2(F&& f, G&& g) {
+        each(f);
+        each(g);
+    }
 };
 
 void turn_trig(double frac, double& c, double& s) {

@@ -352,11 +352,15 @@ struct Stream {
     template <int PI, class Ex>
     static UPX_HD void mid_passes(Ex& ex, cf* lds_all, const cf* tw) {
         if constexpr (PI < PS::n - 1) {
-            ex.each([&](int tid, Thread& th) {
-                read_all(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES);
-                pass_compute<PI>(th, tw, tid % LANES);
-            });
-            ex.each([&](int tid, Thread& th) { pass_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+            // `each2(f, g)`: g scatters into the buffer f has read.  Multi-wave streams need a barrier in
+            // between; a stream inside ONE wave does not (LDS operations of a wave execute in order and every
+            // scattered value depends on all 16 values read), so its executor runs f and g back to back.
+            ex.each2(
+                [&](int tid, Thread& th) {
+                    read_all(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES);
+                    pass_compute<PI>(th, tw, tid % LANES);
+                },
+                [&](int tid, Thread& th) { pass_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
             mid_passes<PI + 1>(ex, lds_all, tw);
         }
     }
@@ -694,13 +698,10 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     };
     // forward transform from the scattered pass 0 to the iFFT input, then the inverse passes
     auto frame_body = [&](int half) {
-        ex.each(scatter0);
         mids();
-        ex.each(zsplit_compute);
-        ex.each(zsplit_write);
+        ex.each2(zsplit_compute, zsplit_write);
         ex.each([&](int tid, Thread& th) { mask(tid, th, half); });
-        ex.each(inv0);
-        ex.each(scatter0);
+        ex.each2(inv0, scatter0);
         mids();
     };
 
@@ -714,21 +715,25 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // (inside this loop) on purpose: two inlined copies may contract multiply-adds differently,
     // and which copy a frame meets would then depend on how the signal is cut into streams.
     for (int it = 0; it <= n_iter; ++it) {
-        ex.each([&](int tid, Thread& th) {
-            if (it > 0) tail_c(tid, th, it - 1);
-            if (it < n_iter) head(tid, th, it, 0);
-        });
+        ex.each2(
+            [&](int tid, Thread& th) {
+                if (it > 0) tail_c(tid, th, it - 1);
+                if (it < n_iter) head(tid, th, it, 0);
+            },
+            [&](int tid, Thread& th) {
+                if (it < n_iter) scatter0(tid, th);
+            });
         if (it == n_iter) break;
         frame_body(0);
-        ex.each([&](int tid, Thread& th) {
-            tail_lr(tid, th, it, 0);
-            head(tid, th, it, 1);
-        });
+        ex.each2(
+            [&](int tid, Thread& th) {
+                tail_lr(tid, th, it, 0);
+                head(tid, th, it, 1);
+            },
+            scatter0);
         frame_body(1);
-        ex.each([&](int tid, Thread& th) { tail_lr(tid, th, it, 1); });
-        ex.each(stage_c);
-        ex.each(inv0);
-        ex.each(scatter0);
+        ex.each2([&](int tid, Thread& th) { tail_lr(tid, th, it, 1); }, stage_c);
+        ex.each2(inv0, scatter0);
         mids();
     }
 }

@@ -50,20 +50,28 @@ int fail(int code, const char* fmt, ...) {
 template <bool WAVE_SYNC, int P>
 struct DevExec {
     upx::ThreadT<P> st;
-    template <class F>
-    __device__ __forceinline__ void each(F&& f) {
-        f((int)threadIdx.x, st);
-#if defined(UPX_EXP) && UPX_EXP >= 6
-        if constexpr (true) {   // timing experiment: no workgroup barriers at all (wrong results)
-#else
+    __device__ __forceinline__ void sync() {
         if constexpr (WAVE_SYNC) {
-#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
             __syncthreads();
         }
+    }
+    template <class F>
+    __device__ __forceinline__ void each(F&& f) {
+        f((int)threadIdx.x, st);
+        sync();
+    }
+    // f reads the stream's LDS buffer, g scatters into it.  Across waves that needs a barrier in between;
+    // inside one wave the LDS executes the wave's operations in order, so f and g run back to back.
+    template <class F, class G>
+    __device__ __forceinline__ void each2(F&& f, G&& g) {
+        f((int)threadIdx.x, st);
+        if constexpr (!WAVE_SYNC) __syncthreads();
+        g((int)threadIdx.x, st);
+        sync();
     }
 };
 
