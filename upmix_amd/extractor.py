@@ -256,14 +256,24 @@ class MultiBandExtractorAccu:
 _PLAN_CACHE: dict = {}
 
 
+def _band_signature(b: "MultiBandExtractorAccu") -> tuple:
+    """Everything that determines a band's device state (ids of Python objects can be recycled, values cannot)."""
+    return (int(b.block_size), int(b.hop_size), float(b.sr), float(b.f_low), float(b.f_high), str(b.xover_mode),
+            float(b.xover_width_low_hz), float(b.xover_width_high_hz),
+            hash(np.asarray(b.analysis_window, dtype=np.float32).tobytes()),
+            hash(np.asarray(b.synthesis_window, dtype=np.float32).tobytes()))
+
+
 def _plan_for(band_extractors: Sequence[MultiBandExtractorAccu], device: int) -> DevicePlan:
-    key = (tuple(id(b) for b in band_extractors), device)
+    key = (tuple(_band_signature(b) for b in band_extractors), device)
     plan = _PLAN_CACHE.get(key)
     if plan is None:
-        if len(_PLAN_CACHE) > 8:
-            _PLAN_CACHE.clear()
+        while len(_PLAN_CACHE) >= 4:                      # small LRU: plans own device memory
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE))).close()
         plan = DevicePlan(band_extractors, device)
-        _PLAN_CACHE[key] = plan
+    else:
+        del _PLAN_CACHE[key]
+    _PLAN_CACHE[key] = plan
     return plan
 
 
