@@ -377,3 +377,47 @@ def test_wav_pipeline_device_codec_and_cli(ux, orc, tmp_path):
     host = cli.run("tone.wav", "split", str(tmp_path / "in"), str(tmp_path / "out_host"), max_stft=4096, host_export=True)
     c_host, _ = wav.read(host["C"])
     assert np.max(np.abs(c_host - c_wav)) <= 2.0 / 32768
+
+
+def test_random_plans_vs_oracle(ux, orc):
+    """Seeded random band plans / overlaps / windows / lengths through whichever kernel path they select."""
+    rng = np.random.default_rng(2024)
+    sizes = [256, 512, 1024, 2048, 4096, 8192, 16384]
+    overlaps = [0.5, 0.75, 0.875, 0.6, 0.7, 0.9]
+    windows = sorted(ux.WINDOW_FUNCS)
+    for trial in range(12):
+        n_bands = int(rng.integers(1, 4))
+        edges = np.sort(rng.uniform(20.0, 15000.0, size=n_bands + 1))
+        overlap = overlaps[int(rng.integers(len(overlaps)))]
+        wname = windows[int(rng.integers(len(windows)))]
+        mode = ["raised_cosine", "hard_zero"][int(rng.integers(2))]
+        total = int(rng.integers(3000, 120000))
+        gb, ob, prev = [], [], 0.0
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            n = sizes[int(rng.integers(len(sizes)))]
+            if int(n * (1 - overlap)) < 1 or -(-n // int(n * (1 - overlap))) > 64:
+                continue
+            width = 0.25 * hi
+            gb.append(ux.MultiBandExtractorAccu(n, overlap, ux.WINDOW_FUNCS[wname], lo, hi, 44100, mode, prev, width))
+            ob.append(orc.Band(n, overlap, lo, hi, 44100, mode, prev, width, window=orc.WINDOWS[wname]))
+            prev = width
+        if not gb:
+            continue
+        x = orc.synthetic_stereo(total, (7, trial))
+        ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+        got = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 44100, gb)
+        for g, r in zip(got, ref):
+            close(g, r)
+
+
+def test_process_rank_single_gpu(ux, orc):
+    """The per-rank entry of the multi-GPU path with world = 1 equals the plain call."""
+    from upmix_amd import sharding
+    x = orc.synthetic_stereo(150000, 15)
+    bands = gpu_chain(ux, [0, 300, 3000], 48000, 4096, 64)
+    plan = ux.DevicePlan(bands)
+    shard, outs = sharding.process_rank(plan, x, 0, 1)
+    assert shard.own_len == len(x)
+    for a, b in zip(outs, plan.process(x)):
+        assert np.array_equal(a, b)
+    plan.close()

@@ -139,6 +139,36 @@ def process_sharded_single_device(plan, stereo: np.ndarray, max_shard: int = 1 <
     return tuple(outs)
 
 
+def process_rank(plan, stereo: np.ndarray, rank: int, world: int, seam: Optional["RcclSeam"] = None):
+    """
+    One rank's share of a time-sharded run on its own GPU (one process per GPU):
+    upload shard `rank` of `stereo` (+ right halo), run every band, exchange the overlap-add seam over
+    RCCL and return (shard, (center, left, right)) for the samples this rank owns.
+    `stereo` is the whole [T,2] signal (a memory-mapped file is fine: only the shard is touched).
+    """
+    geo = ShardGeometry(plan.block_sizes, plan.hops)
+    shard = geo.plan(stereo.shape[0], world)[rank]
+    if world > 1 and seam is None:
+        raise ValueError("a multi-rank run needs an RcclSeam")
+    spill = geo.spill if world > 1 else 0
+    local = np.ascontiguousarray(stereo[shard.start:shard.start + shard.t_in], dtype=np.float32)
+    d_in = plan.alloc(max(shard.t_in, 1) * 8)
+    planes = [plan.alloc((shard.own_len + spill) * 4) for _ in range(3)]
+    try:
+        plan.h2d(d_in, local)
+        plan.process_device(d_in, shard.t_in, shard.own_len, planes[0], planes[1], planes[2], shard.t_out)
+        if world > 1:
+            seam.exchange(planes, shard.own_len, spill)
+        outs = [np.empty(shard.own_len, dtype=np.float32) for _ in range(3)]
+        for o, d in zip(outs, planes):
+            plan.d2h(o, d)
+    finally:
+        plan.free(d_in)
+        for d in planes:
+            plan.free(d)
+    return shard, tuple(outs)
+
+
 class RcclSeam:
     """One RCCL communicator per process/GPU for the seam all-reduce (upx_comm_* in the C ABI)."""
 
