@@ -69,8 +69,14 @@ def cpu_baseline(target_seconds=15.0):
         total, dt = run(sample_seconds)
     else:
         sample_seconds = 10.0
+    # the same frame loops one band after the other (no thread pool): SURVEY 8(d) asks for both
+    xs = synth(int(SR * 10.0), 2).astype(np.float64)
+    t0 = time.perf_counter()
+    orc.extract_multi_band(xs[:, 0], xs[:, 1], bands, per_band=orc.band_process_streaming)
+    serial = len(xs) / (time.perf_counter() - t0) / 1e6
     return {
         "value": round(total / dt / 1e6, 4), "unit": "Msamples/s", "cores": len(bands), "kind": "port",
+        "bands_serial_value": round(serial, 4),
         "sample": f"first {sample_seconds:g} s of the same workload (seed 2), oracle/upmix_oracle.py "
                   f"extract_multi_band_threadpool: ThreadPoolExecutor(), one task per band (={len(bands)} threads), "
                   f"float64 numpy.fft, {os.cpu_count()} host cpus visible, {dt:.1f} s wall",
