@@ -146,7 +146,7 @@ extern "C" int emu_big_band(int log2n, int hop, const float* in, long long t_in,
     a.j_lo = j_lo; a.j_hi = j_hi; a.accumulate = accumulate;
     a.n_gain = n_gain; a.gain_stride = (1 << log2n) / 2 + 1;
 #define UPX_BIG(L) if (log2n == L) return run_big<upx::BigCfg<L>>(a, m_lo, m_hi, chunk_frames);
-    UPX_BIG(8) UPX_BIG(9) UPX_BIG(10) UPX_BIG(11) UPX_BIG(12) UPX_BIG(13) UPX_BIG(14) UPX_BIG(15) UPX_BIG(16)
+    UPX_BIG(6) UPX_BIG(7) UPX_BIG(8) UPX_BIG(9) UPX_BIG(10) UPX_BIG(11) UPX_BIG(12) UPX_BIG(13) UPX_BIG(14) UPX_BIG(15) UPX_BIG(16)
 #undef UPX_BIG
     return -1;
 }

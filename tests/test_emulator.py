@@ -181,7 +181,8 @@ def test_arbitrary_hops_unfused_path(emu):
     """Hops that do not divide N (hop = int(N (1 - overlap)), center_extraction.py:252) and K = 16."""
     if PTS[0] != 16:
         pytest.skip("the unfused path has one build")
-    for n, ov, wname, total, ch in ((512, 0.6, "hamming", 6000, 12), (1024, 0.7, "hann", 9000, 10),
+    for n, ov, wname, total, ch in ((64, 0.75, "hann", 2000, 40), (128, 0.5, "blackman_harris", 3000, 20),
+                                    (512, 0.6, "hamming", 6000, 12), (1024, 0.7, "hann", 9000, 10),
                                     (256, 0.9375, "hann", 3000, 40), (2048, 0.35, "sqrt_hann", 12000, 6),
                                     (4096, 0.8, "blackman_harris", 30000, 12), (16384, 0.6, "hann", 80000, 8)):
         band = orc.Band(n, ov, 200., 8000., 44100, "raised_cosine", 50., 2000., window=orc.WINDOWS[wname])

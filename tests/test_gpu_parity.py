@@ -84,8 +84,8 @@ def test_golden_other_overlaps_and_windows(ux):
 
 def test_unsupported_shapes_fail_loudly(ux):
     x = np.zeros((4000, 2), np.float32)
-    # sizes outside 256..65536 are not covered
-    bex = ux.MultiBandExtractorAccu(128, 0.75, ux.make_hann, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
+    # sizes outside 64..65536 are not covered
+    bex = ux.MultiBandExtractorAccu(32, 0.75, ux.make_hann, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
     with pytest.raises(NotImplementedError):
         bex.process_all_blocks(x[:, 0], x[:, 1])
     # more than 64 frames overlapping one sample (hop = 2 of 256) is refused, not silently slow
@@ -105,7 +105,7 @@ def test_arbitrary_overlap_unfused_path(ux, orc, monkeypatch):
     for got, k in zip(bex.process_all_blocks(x[:, 0], x[:, 1]), "clr"):
         close(got, z[f"ov60_hamming_{k}"])
     x = orc.synthetic_stereo(300000, 13)
-    for n, ov, wname in ((1024, 0.7, "hann"), (256, 0.9375, "hann"), (2048, 0.35, "sqrt_hann"),
+    for n, ov, wname in ((64, 0.75, "hann"), (128, 0.75, "blackman_harris"), (1024, 0.7, "hann"), (256, 0.9375, "hann"), (2048, 0.35, "sqrt_hann"),
                          (4096, 0.8, "blackman_harris"), (8192, 0.9, "blackman"), (16384, 0.6, "hann")):
         gb = ux.MultiBandExtractorAccu(n, ov, ux.WINDOW_FUNCS[wname], 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0)
         ob = orc.Band(n, ov, 200.0, 8000.0, 44100, "raised_cosine", 50.0, 2000.0, window=orc.WINDOWS[wname])

@@ -137,7 +137,7 @@ def test_c_abi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.upx_abi_version() == 1
     assert lib.upx_supported(8192, 2048) == 1 and lib.upx_supported(65536, 16384) == 1
-    assert lib.upx_supported(131072, 32768) == 0 and lib.upx_supported(128, 32) == 0
+    assert lib.upx_supported(131072, 32768) == 0 and lib.upx_supported(128, 32) == 1 and lib.upx_supported(32, 8) == 0
     assert lib.upx_supported(512, 204) == 1 and lib.upx_supported(256, 2) == 0   # any hop, <= 64 frames per sample
 
 

@@ -53,7 +53,7 @@ struct BigCfg {
     static constexpr int N1 = LOG2N >= 14 ? 16 : 1;      // radix of the global step (1: the frame fits one LDS row)
     static constexpr int N2 = N / N1;
     static constexpr int LOG2N2 = LOG2N >= 14 ? LOG2N - 4 : LOG2N;
-    using Row = Cfg<LOG2N2, 4, 16>;                      // the N2-point row transform (its K is unused)
+    using Row = Cfg<LOG2N2, 4, (LOG2N2 >= 8 ? 16 : 8)>;   // the N2-point row transform (its K is unused); 8 points per lane below 256
     // bin k -> scratch offset after the forward transform
     UPX_HD static int scr(int i) { return N1 == 1 ? i : (i & 15) * N2 + (i >> 4); }
 };

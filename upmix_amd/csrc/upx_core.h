@@ -199,6 +199,8 @@ template <> struct Passes<10, 16> { static constexpr int n = 3; static constexpr
 template <> struct Passes<11, 16> { static constexpr int n = 3; static constexpr int r[6] = {16, 16, 8, 1, 1, 1}; };
 template <> struct Passes<12, 16> { static constexpr int n = 3; static constexpr int r[6] = {16, 16, 16, 1, 1, 1}; };
 template <> struct Passes<13, 16> { static constexpr int n = 4; static constexpr int r[6] = {16, 16, 16, 2, 1, 1}; };
+template <> struct Passes<6, 8>   { static constexpr int n = 2; static constexpr int r[6] = {8, 8, 1, 1, 1, 1}; };
+template <> struct Passes<7, 8>   { static constexpr int n = 3; static constexpr int r[6] = {8, 8, 2, 1, 1, 1}; };
 template <> struct Passes<8, 8>   { static constexpr int n = 3; static constexpr int r[6] = {8, 8, 4, 1, 1, 1}; };
 template <> struct Passes<9, 8>   { static constexpr int n = 3; static constexpr int r[6] = {8, 8, 8, 1, 1, 1}; };
 template <> struct Passes<10, 8>  { static constexpr int n = 4; static constexpr int r[6] = {8, 8, 8, 2, 1, 1}; };

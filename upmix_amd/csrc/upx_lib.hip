@@ -262,7 +262,7 @@ const BigEntry* find_big(int log2n) {
     static const std::map<int, BigEntry> table = [] {
         std::map<int, BigEntry> t;
 #define UPX_BIG(L) t[L] = BigImpl<upx::BigCfg<L>>::get();
-        UPX_BIG(8) UPX_BIG(9) UPX_BIG(10) UPX_BIG(11) UPX_BIG(12) UPX_BIG(13) UPX_BIG(14) UPX_BIG(15) UPX_BIG(16)
+        UPX_BIG(6) UPX_BIG(7) UPX_BIG(8) UPX_BIG(9) UPX_BIG(10) UPX_BIG(11) UPX_BIG(12) UPX_BIG(13) UPX_BIG(14) UPX_BIG(15) UPX_BIG(16)
 #undef UPX_BIG
         return t;
     }();
@@ -446,7 +446,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         if (!upx_supported(block_size[b], hop[b]))
             return fail(UPX_ERR_UNSUPPORTED,
                         "band %d: STFT size %d with hop %d is not covered by the gfx950 kernels "
-                        "(power-of-two sizes 256..65536, at most 64 frames overlapping a sample)",
+                        "(power-of-two sizes 64..65536, at most 64 frames overlapping a sample)",
                         b, block_size[b], hop[b]);
     }
     int n_dev = 0;
