@@ -51,7 +51,9 @@ const char* upx_last_error(void);
 /* Number of visible HIP devices. */
 int upx_device_count(int* count);
 
-/* 1 if (block_size, hop) is covered by the gfx950 kernels, else 0. */
+/* 1 if (block_size, hop) is covered by the gfx950 kernels, else 0: power-of-two sizes 64..65536, any hop in
+   [1, N] with at most 64 frames overlapping one sample.  hop = N/2, N/4, N/8 with N in 256..8192 takes the fused
+   streaming kernel, everything else the unfused pipeline. */
 int upx_supported(int32_t block_size, int32_t hop);
 
 /*
@@ -76,7 +78,9 @@ int upx_plan_set_blocks_per_stream(upx_plan* plan, int band, int blocks);
  *   stereo  interleaved float32 [T][2] (L, R)
  *   out_c/out_l/out_r  float32 [T] each: centre, left-side, right-side
  * Replaces extract_center_left_right_multi_band_in_memory (:477-513); same
- * (center, left, right) order.
+ * (center, left, right) order.  n_samples < 2^29 per call (byte offsets are 32-bit inside the
+ * kernels); longer signals are time-sharded by the caller with upx_process_device +
+ * upx_seam_add_local (upmix_amd/sharding.py does this transparently).
  */
 int upx_process(upx_plan* plan, const float* stereo, int64_t n_samples, float* out_c, float* out_l, float* out_r);
 
