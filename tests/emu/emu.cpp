@@ -38,10 +38,14 @@ int run(upx::BandArgs a) {
     std::vector<upx::cf> tw((size_t)C::TW_CF);
     upx::fill_twiddles<C>(tw.data(), turn_trig);
     a.tw = tw.data();
-    const long long n_blocks = (long long)a.m_hi - a.m_lo;
-    if (n_blocks <= 0) return 0;
+    a.blocks_per_stream += a.blocks_per_stream & 1;              // the kernel needs an even F (the library rounds up too)
+    const long long n_blocks = (long long)a.m_hi - a.m_lo + 1;   // streams start one frame early (frame m_lo - 1)
+    if (a.m_hi <= a.m_lo) return 0;
     const long long n_streams = (n_blocks + a.blocks_per_stream - 1) / a.blocks_per_stream;
     const long long n_wg = (n_streams + C::G - 1) / C::G;
+    const int tail = (C::P - C::HS) * C::LANES;
+    std::vector<float> seam((size_t)n_wg * C::G * 3 * tail, NAN);
+    a.seam = seam.data();
     std::vector<upx::cf> lds((size_t)C::LDS_CF);
     for (long long wg = 0; wg < n_wg; ++wg) {
         SeqExec<C::P> ex;
@@ -50,6 +54,7 @@ int run(upx::BandArgs a) {
         for (auto& v : lds) v = upx::mk(NAN, NAN);
         upx::band_program<C>(ex, a, lds.data(), (int)wg);
     }
+    for (long long g = 0; g < n_streams * tail; ++g) upx::stream_seam_add(a, (int)n_streams, tail, C::HOP, g);
     return 0;
 }
 }   // namespace

@@ -268,6 +268,7 @@ struct BandArgs {
     int n_gain;
     int gain_stride;
     int accumulate;        // 0: out = band, 1: out += band (band sum in list order)
+    float* seam;           // [streams][3][(K-1) hop]: what a stream's last frames add to the NEXT stream's first blocks
 };
 
 constexpr float kEps = 1e-12f;   // center_extraction.py:36
@@ -396,12 +397,14 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     constexpr int LAST = PS::n - 1; // final pass index
     constexpr int SP = C::SPITCH;
 
-    // Frames are transformed in pairs (a, b) = (odd j, j+1) so that one inverse FFT
-    // returns the centre signal of both.  With F even and m_lo even every stream
-    // starts on an 'a' frame (m0-(K-1) is odd), so the pairing - and therefore every
-    // rounding - is independent of blocks_per_stream, CU count and sharding.
-    const int F = a.blocks_per_stream;
-    const int n_iter = (F + K + 1) / 2;   // frame pairs covering m0-(K-1) .. m0+F
+    // A stream transforms the F frames [m0, m0+F), m0 = m_lo - 1 + stream * F, and nothing else: no halo
+    // frames are recomputed.  Frames come in pairs (a, b) = (odd j, j+1) so that one inverse FFT returns the
+    // centre signal of both; with m_lo and F even every stream starts on an 'a' frame and the pairing is the
+    // same for every partition.  Block m = sum of frames m-K+1..m: the K-1 blocks after m0+F-1 are only
+    // partially known here (the "tail") and go to a.seam; upx_stream_seam_add() adds each tail onto the first
+    // blocks of the next stream afterwards (same float32 association as the multi-GPU seam).
+    const int F = a.blocks_per_stream;   // even (host guarantees): a stream is a whole number of frame pairs
+    const int n_iter = F / 2;
 
     cf* const tw = lds_all + C::G * C::PITCH;   // LDS twiddle table, after the stream buffers
 
@@ -416,13 +419,9 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // previous frame (L2 hits); the HS "new hop" slots are HBM misses, so they are fetched one frame
     // ahead into th.pre and only consumed here.
     auto frame_of = [&](int tid, int it, int half, bool& exists) {
-        const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
-        const int j = m0 - (K - 1) + 2 * it + half;
-        const int j_first = m0 - (K - 1) > a.j_lo ? m0 - (K - 1) : a.j_lo;
-        // one frame past the emitted range is still transformed: it is the pair partner of
-        // frame m0+F-1 (for even F), and pairing must not depend on how streams are cut
-        const int j_end = m0 + F + 1 < a.j_hi ? m0 + F + 1 : a.j_hi;
-        exists = j >= j_first && j < j_end;
+        const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
+        const int j = m0 + 2 * it + half;
+        exists = j >= a.j_lo && j < a.j_hi && j < m0 + F;
         return j;
     };
     auto prefetch = [&](int tid, Thread& th, int it, int half) {
@@ -476,10 +475,9 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // so that their HBM latency overlaps the butterflies
     auto tail_lr = [&](int tid, Thread& th, int it, int half) {
         const int lane = tid % LANES;
-        const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
-        const int j = m0 - (K - 1) + 2 * it + half;
-        const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
-        const bool emit = j >= m0 && j < m_end;
+        const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
+        const int j = m0 + 2 * it + half;
+        const bool emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
         const int e = emit ? j * HOP + lane : 0;
         UPX_GLOBAL float* out_l = opaque(a.out_l);
         UPX_GLOBAL float* out_r = opaque(a.out_r);
@@ -532,16 +530,15 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     };
     auto tail_c = [&](int tid, Thread& th, int it) {
         const int lane = tid % LANES;
-        const int m0 = a.m_lo + (wg_index * C::G + tid / LANES) * F;
-        const int m_end = m0 + F < a.m_hi ? m0 + F : a.m_hi;
+        const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
         UPX_GLOBAL float* out_c = opaque(a.out_c);
         const int last = a.t_out - 1;
-        const int ja = m0 - (K - 1) + 2 * it;
+        const int ja = m0 + 2 * it;
         float old_c[2][HS];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int j = ja + half;
-            const bool emit = j >= m0 && j < m_end;
+            const bool emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
             const int e = emit ? j * HOP + lane : 0;
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
@@ -569,7 +566,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
             for (int s = 0; s < P; ++s)   // swapped output: c_a = Re y = x.y ; c_b = Im y = x.x
                 th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w[s];
-            const bool emit = j >= m0 && j < m_end;
+            const bool emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
             const int e = emit ? j * HOP + lane : 0;
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
@@ -738,6 +735,33 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         ex.each2(inv0, scatter0);
         mids();
     }
+    // what is left in the accumulators belongs to the K-1 blocks after this stream
+    ex.each([&](int tid, Thread& th) {
+        const int lane = tid % LANES;
+        const int sid = wg_index * C::G + tid / LANES;
+        UPX_GLOBAL float* seam = opaque(a.seam) + (size_t)sid * 3 * (P - HS) * LANES + lane;
+#pragma unroll
+        for (int s = 0; s < P - HS; ++s) {
+            seam[(0 * (P - HS) + s) * LANES] = th.acc_c[s];
+            seam[(1 * (P - HS) + s) * LANES] = th.acc_l[s];
+            seam[(2 * (P - HS) + s) * LANES] = th.acc_r[s];
+        }
+    });
+}
+
+// Adds the tail of stream `sid` onto the first blocks of stream sid+1; one call per (sid, i), i < (K-1) hop.
+// (host / a trivial kernel; see BandArgs::seam)
+UPX_HD void stream_seam_add(const BandArgs& a, int n_streams, int tail, int hop, long long gid) {
+    const int sid = (int)(gid / tail), i = (int)(gid % tail);
+    if (sid >= n_streams - 1) return;                       // the last stream's tail lies beyond the emitted range
+    const long long m = (long long)a.m_lo - 1 + (long long)(sid + 1) * a.blocks_per_stream;
+    const long long n = m * hop + i;
+    if (m >= a.m_hi || n < 0 || n >= a.t_out) return;
+    if (m + i / hop >= a.m_hi) return;                      // blocks past the emitted range stay untouched
+    const float* row = a.seam + (size_t)sid * 3 * tail;
+    a.out_c[n] += row[i];
+    a.out_l[n] += row[tail + i];
+    a.out_r[n] += row[2 * tail + i];
 }
 
 // Host-side helper: fill the compact twiddle table for Cfg (double precision -> float).

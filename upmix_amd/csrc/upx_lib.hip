@@ -83,6 +83,12 @@ __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     upx::band_program<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 
+__global__ void upx_stream_seam_add_kernel(upx::BandArgs a, int n_streams, int tail, int hop) {
+    const long long total = (long long)n_streams * tail;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x)
+        upx::stream_seam_add(a, n_streams, tail, hop, g);
+}
+
 __global__ void upx_absmax_kernel(const float* x, long long n, unsigned int* result) {
     float m = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -349,6 +355,8 @@ struct upx_plan {
     bool timed_once = false;
     unsigned int* d_scalar = nullptr;
     float pipe_ms[3] = {0.f, 0.f, 0.f};
+    float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
+    size_t seam_floats = 0;
     upx::cf* d_scratch = nullptr;   // z | y | yc of the big path (shared by all big bands)
     size_t scratch_cf = 0;
 };
@@ -568,6 +576,7 @@ void upx_plan_destroy(upx_plan* p) {
     for (auto& kv : p->tw) (void)hipFree(kv.second);
     if (p->d_scalar) (void)hipFree(p->d_scalar);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_seam) (void)hipFree(p->d_seam);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -674,17 +683,28 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             s.last_f = emit;
             continue;
         }
-        // blocks per stream: fill every resident workgroup slot once, never fewer than 8 blocks
+        // blocks per stream: fill every resident workgroup slot once; even (whole frame pairs), at least 8 and at
+        // least K (a stream's tail must end inside the next stream).  Streams cover frames m_lo-1 .. m_hi-1.
         int resident = (s.kern->wpe * 256) / s.kern->wg;              // workgroups per CU by registers
         const int by_lds = (160 * 1024) / s.kern->lds_bytes;              // ... and by LDS
         if (resident > by_lds) resident = by_lds;
         if (resident < 1) resident = 1;
         long long target_streams = (long long)p->n_cu * resident * s.kern->g;
-        long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + target_streams - 1) / target_streams;
+        long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + 1 + target_streams - 1) / target_streams;
         if (s.blocks_override <= 0 && f < 8) f = 8;
-        f += f & 1;   // even: keeps the (odd, even) frame pairing identical for every partition
-        const long long n_streams = (m_hi + f - 1) / f;
+        if (f < s.k) f = s.k;
+        f += f & 1;
+        const long long n_streams = (m_hi + 1 + f - 1) / f;
         const long long n_wg = (n_streams + s.kern->g - 1) / s.kern->g;
+        const long long tail = (long long)(s.k - 1) * s.hop;
+        const size_t seam_need = (size_t)n_wg * s.kern->g * 3 * tail;
+        if (seam_need > p->seam_floats) {
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            if (p->d_seam) HIP_TRY(hipFree(p->d_seam));
+            p->d_seam = nullptr;
+            HIP_TRY(hipMalloc(&p->d_seam, seam_need * sizeof(float)));
+            p->seam_floats = seam_need;
+        }
         upx::BandArgs a;
         a.in = reinterpret_cast<const upx::cf*>(d_stereo);
         a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
@@ -694,10 +714,14 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
         a.blocks_per_stream = (int)f;
         a.accumulate = b == 0 ? 0 : 1;
+        a.seam = p->d_seam;
         s.last_wg = (int)n_wg;
         s.last_f = (int)f;
         if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
         s.kern->launch(a, (int)n_wg, p->stream);
+        if (n_streams > 1)
+            hipLaunchKernelGGL(upx_stream_seam_add_kernel, dim3(grid_for(n_streams * tail)), dim3(256), 0, p->stream, a,
+                               (int)n_streams, (int)tail, s.hop);
         if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
     }
     HIP_TRY(hipGetLastError());
