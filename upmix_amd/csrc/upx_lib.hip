@@ -50,7 +50,10 @@ int fail(int code, const char* fmt, ...) {
 template <bool WAVE_SYNC, int P>
 struct DevExec {
     upx::ThreadT<P> st;
+    // Threads only communicate through LDS, so the fences order LDS accesses only ("local"): global loads and
+    // stores (audio, windows, gains, output planes) may stay in flight across a phase boundary.
     __device__ __forceinline__ void sync() {
+#if defined(UPX_FULL_FENCES)
         if constexpr (WAVE_SYNC) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -58,6 +61,17 @@ struct DevExec {
         } else {
             __syncthreads();
         }
+#else
+        if constexpr (WAVE_SYNC) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+#endif
     }
     template <class F>
     __device__ __forceinline__ void each(F&& f) {
@@ -69,7 +83,7 @@ struct DevExec {
     template <class F, class G>
     __device__ __forceinline__ void each2(F&& f, G&& g) {
         f((int)threadIdx.x, st);
-        if constexpr (!WAVE_SYNC) __syncthreads();
+        if constexpr (!WAVE_SYNC) sync();
         g((int)threadIdx.x, st);
         sync();
     }
