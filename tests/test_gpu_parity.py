@@ -423,3 +423,28 @@ def test_process_rank_single_gpu(ux, orc):
     for a, b in zip(outs, plan.process(x)):
         assert np.array_equal(a, b)
     plan.close()
+
+
+def test_pathological_signals(ux, orc):
+    """Impulses, DC, full-scale square-ish content, large and small amplitudes: relative 1e-5 RMS vs the oracle."""
+    total = 60000
+    t = np.arange(total)
+    rng = np.random.default_rng(21)
+    cases = {
+        "impulse": np.stack([(t == 12345) * 1.0, (t == 12345) * 0.5], axis=1),
+        "dc": np.stack([np.full(total, 0.25), np.full(total, -0.1)], axis=1),
+        "square": np.stack([np.sign(np.sin(2 * np.pi * 440 * t / 48000)), np.sign(np.sin(2 * np.pi * 443 * t / 48000))], axis=1) * 0.9,
+        "loud_1e6": rng.standard_normal((total, 2)) * 1e6,
+        "quiet_1e-5": rng.standard_normal((total, 2)) * 1e-5,
+        "sine_left_only": np.stack([np.sin(2 * np.pi * 1000 * t / 48000), np.zeros(total)], axis=1),
+    }
+    bands = gpu_chain(ux, [0, 30, 120, 480, 1920, 7680], 48000, 8192, 32)
+    ob = orc.plan_bands([0, 30, 120, 480, 1920, 7680], 0.75, orc.win_blackman_harris, 48000, max_block_size=8192)
+    for name, x in cases.items():
+        x = x.astype(np.float32)
+        ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+        got = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, bands)
+        scale = max(float(np.max(np.abs(x))), 1e-30)
+        for g, r in zip(got, ref):
+            assert np.all(np.isfinite(g)), name
+            assert rms((g.astype(np.float64) - r) / scale) <= TOL, name
