@@ -5,7 +5,9 @@
 // layout and framing logic against the oracle without a GPU.  The product
 // (upmix_amd) never loads this library.
 #include <cmath>
+#include <type_traits>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "../../upmix_amd/csrc/upx_core.h"
@@ -25,6 +27,35 @@ struct SeqExec {
         each(f);
         each(g);
     }
+    void wg_barrier() {}
+};
+
+// Wide streams: `each` orders ONE wave only, waves meet at wg_barrier().  Between two barriers the waves are run one
+// after the other, each through all of its phases (alternately first-to-last and last-to-first wave): a legal
+// schedule on the GPU, and the one that exposes a missing barrier as a read of poisoned or stale LDS.
+template <int PTS>
+struct WaveExec {
+    using Thread = upx::ThreadT<PTS>;
+    std::vector<Thread> st;
+    std::vector<std::function<void(int, Thread&)>> pending;
+    bool flip = false;
+    template <class F>
+    void each(F&& f) { pending.emplace_back(f); }
+    template <class F, class G>
+    void each2(F&& f, G&& g) {
+        pending.emplace_back(f);
+        pending.emplace_back(g);
+    }
+    void wg_barrier() {
+        const int n_waves = (int)st.size() / 64;
+        for (int i = 0; i < n_waves; ++i) {
+            const int w = flip ? n_waves - 1 - i : i;
+            for (auto& ph : pending)
+                for (int t = w * 64; t < w * 64 + 64; ++t) ph(t, st[t]);
+        }
+        pending.clear();
+        flip = !flip;
+    }
 };
 
 void turn_trig(double frac, double& c, double& s) {
@@ -36,8 +67,13 @@ void turn_trig(double frac, double& c, double& s) {
 template <class C>
 int run(upx::BandArgs a) {
     std::vector<upx::cf> tw((size_t)C::TW_CF);
-    upx::fill_twiddles<C>(tw.data(), turn_trig);
+    upx::fill_tables<C>(tw.data(), turn_trig);
     a.tw = tw.data();
+    // the gain rows in the order the kernel reads them (the library does the same at plan creation)
+    std::vector<float> gain((size_t)a.n_gain * a.gain_stride);
+    for (int q = 0; q < a.n_gain; ++q)
+        for (int i = 0; i <= C::N / 2; ++i) gain[(size_t)q * a.gain_stride + i] = a.gain[(size_t)q * a.gain_stride + upx::gain_bin<C>(i)];
+    a.gain = gain.data();
     a.blocks_per_stream += a.blocks_per_stream & 1;              // the kernel needs an even F (the library rounds up too)
     const long long n_blocks = (long long)a.m_hi - a.m_lo + 1;   // streams start one frame early (frame m_lo - 1)
     if (a.m_hi <= a.m_lo) return 0;
@@ -48,7 +84,7 @@ int run(upx::BandArgs a) {
     a.seam = seam.data();
     std::vector<upx::cf> lds((size_t)C::LDS_CF);
     for (long long wg = 0; wg < n_wg; ++wg) {
-        SeqExec<C::P> ex;
+        typename std::conditional<C::WIDE, WaveExec<C::P>, SeqExec<C::P>>::type ex;
         ex.st.resize(C::WG);
         // poison LDS so that reads of never-written cells are visible
         for (auto& v : lds) v = upx::mk(NAN, NAN);
@@ -78,6 +114,10 @@ extern "C" int emu_band(int log2n, int k_overlap, int pts, const float* in, long
     UPX_CASE(8, 4, 8) UPX_CASE(9, 4, 8) UPX_CASE(10, 4, 8) UPX_CASE(11, 4, 8) UPX_CASE(12, 4, 8) UPX_CASE(13, 4, 8)
     UPX_CASE(8, 2, 8) UPX_CASE(10, 2, 8) UPX_CASE(10, 8, 8) UPX_CASE(12, 8, 8) UPX_CASE(13, 2, 8)
 #undef UPX_CASE
+    // pts == 0: wide streams (N = 4096, 8192)
+#define UPX_WIDE(L, K) if (log2n == L && k_overlap == K && pts == 0) return run<upx::WideCfg<L, K>>(a);
+    UPX_WIDE(12, 4) UPX_WIDE(13, 4) UPX_WIDE(12, 2) UPX_WIDE(12, 8) UPX_WIDE(13, 2) UPX_WIDE(13, 8)
+#undef UPX_WIDE
     return -1;
 }
 

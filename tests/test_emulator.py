@@ -18,7 +18,10 @@ fp = ctypes.POINTER(ctypes.c_float)
 PTS = [16]   # points per lane used by run_emu (switched by the `pts` fixture)
 
 
-@pytest.fixture(autouse=True, params=[16, 8], ids=["P16", "P8"])
+WIDE = "wide"   # wide streams for N = 4096 / 8192 (the library's default there), 16 points per lane otherwise
+
+
+@pytest.fixture(autouse=True, params=[16, 8, WIDE], ids=["P16", "P8", "wide"])
 def pts(request):
     PTS[0] = request.param
     return request.param
@@ -43,6 +46,8 @@ def run_emu(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=No
             gain_table=None):
     pts = pts or PTS[0]
     n, hop = band.block_size, band.hop_size
+    if pts == WIDE:
+        pts = 0 if n in (4096, 8192) else 16
     k = n // hop
     t_in = len(x)
     own = t_in if own_len is None else own_len

@@ -231,9 +231,55 @@ struct Cfg {
     static constexpr int TW_CF = tw_offset(PS::r, PS::n) > 0 ? tw_offset(PS::r, PS::n) : 1;   // twiddle table entries
     static constexpr int LDS_CF = G * PITCH + TW_CF;     // stream buffers + twiddle table
     static constexpr bool WAVE_SYNC = LANES <= 64;       // a stream lives inside one wave: no workgroup barrier needed
+    static constexpr bool WIDE = false;
+    using Sub = Cfg;                                     // the FFT that runs through LDS is the whole frame
     static_assert(K_ == 2 || K_ == 4 || K_ == 8 || K_ == 16, "hop must be N/2, N/4, N/8 or N/16");
     static_assert(P_ % K_ == 0 && P_ >= K_, "hop must be a whole number of register slots");
     static_assert(LANES % P_ == 0 && WG <= 1024, "unsupported size");
+};
+
+// ---------------------------------------------------------------------------
+// Wide streams (N = 4096, 8192): the frame spans 4 / 8 waves.  A plain Stockham schedule makes every pass a
+// workgroup-wide exchange (two s_barriers each), and the waves of the only resident workgroup then move in
+// lock-step: LDS phases and butterfly phases never overlap.  Here the same radix schedule is routed so that all
+// but ONE exchange per transform stay inside a wave:
+//   N = 16 * N2:  radix-16 over n1 in registers (lane n2 holds x[n2 + N2 n1]), * W_N^(k1 n2),
+//                 transposed write -> | s_barrier | -> sixteen N2-point sub-FFTs over n2, one per k1,
+//                 each living in N2/16 lanes of ONE wave (Stockham through that wave's LDS region, wave-level
+//                 ordering only) -> X[k1 + 16 k2].
+// Sub-FFT g holds k1 = (g even ? g/2 : 16 - g/2) (g = 0, 1 hold k1 = 0, 8), so a bin and its mirror N-k sit in
+// sub-FFTs g and g^1 of the SAME wave: the L/R split, the mask and the construction of the inverse input need no
+// barrier either.  The inverse runs the mirror image (sub-FFTs, * W_N^(k1 n2), | s_barrier |, radix-16 over k1),
+// which lands sample n2 + N2 n1 in slot n1 of lane n2 - the overlap-add layout.  Between the two barriers of a
+// transform pair each wave runs ~10 phases on its own, so the two waves of a SIMD drift apart and one computes
+// while the other exchanges.  Cross-wave phases touch lane-private cells (g(r), n2 = lane), r = 0..15.
+// ---------------------------------------------------------------------------
+constexpr int wide_sub_of_k1(int k1) { return k1 == 0 ? 0 : k1 == 8 ? 1 : k1 < 8 ? 2 * k1 : 2 * (16 - k1) + 1; }
+constexpr int wide_k1_of_sub(int g) { return (g & 1) ? ((g >> 1) ? 16 - (g >> 1) : 8) : (g >> 1); }
+
+template <int LOG2N_, int K_>
+struct WideCfg {
+    static constexpr int LOG2N = LOG2N_;
+    static constexpr int N = 1 << LOG2N_;
+    static constexpr int K = K_;
+    static constexpr int P = 16;
+    static constexpr int HOP = N / K_;
+    static constexpr int LANES = N / 16;                 // = N2; lane n2 owns samples n2 + N2 n1
+    static constexpr int WG = LANES;
+    static constexpr int G = 1;
+    static constexpr int HS = 16 / K_;
+    using Sub = Cfg<LOG2N_ - 4, K_, 16>;                 // the N2-point sub-FFT (K is not used by it)
+    static constexpr int SPITCH = Sub::SPITCH;           // slot step inside a sub-FFT buffer
+    static constexpr int PITCH = 16 * Sub::PITCH;        // sixteen sub-FFT buffers
+    static constexpr int BT_ROW = LANES + 1;             // row pitch of W_N^(k1 n2), k1 = 0..15 (odd: the backend cannot
+                                                         // pair two rows into a half-rate ds_read2_b64 / ds_read2st64_b64)
+    static constexpr int BT_CF = 16 * BT_ROW;
+    static constexpr int TW_CF = Sub::TW_CF + BT_CF;     // sub-FFT twiddles, then the big table
+    static constexpr int LDS_CF = PITCH + TW_CF;
+    static constexpr bool WAVE_SYNC = false;
+    static constexpr bool WIDE = true;
+    static_assert(LOG2N_ == 12 || LOG2N_ == 13, "wide streams cover N = 4096 and 8192");
+    static_assert(64 % Sub::LANES == 0 && (64 / Sub::LANES) % 2 == 0, "a wave holds whole (g, g^1) pairs of sub-FFTs");
 };
 
 // LDS index padding: one spare complex after every P, so that the stride-P
@@ -297,6 +343,8 @@ struct ThreadT {
     cf cs[P / 2];     // centre spectrum of the pair: C_a, then Yc[k]
     cf part[P / 2];   // Yc[N-k] of the pair
     cf pre[P];        // (first P/K used) raw samples of the NEXT frame's new hop, fetched one frame ahead
+    float g0[P / 2];  // first gain slot of the own bins, fetched one phase ahead of the mask
+    float gn[2];      // first two gain slots of the Nyquist bin
 };
 
 template <class C>
@@ -389,13 +437,17 @@ struct Stream {
 // ---------------------------------------------------------------------------
 template <class C, class Ex>
 UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
-    using S = Stream<C>;
-    using PS = typename C::PS;
+    using SC = typename C::Sub;     // the FFT that goes through LDS: the frame itself, or a wide stream's sub-FFT
+    using S = Stream<SC>;
+    using PS = typename SC::PS;
     using Thread = ThreadT<C::P>;
     constexpr int N = C::N, LANES = C::LANES, P = C::P, HS = C::HS, HOP = C::HOP, K = C::K;
     constexpr int H = P / 2;        // slots holding own bins k < N/2
     constexpr int LAST = PS::n - 1; // final pass index
     constexpr int SP = C::SPITCH;
+    constexpr int SL = SC::LANES;   // lanes per LDS buffer (= LANES unless wide)
+    constexpr int BUF = SC::PITCH;  // complex per LDS buffer
+    constexpr bool WIDE = C::WIDE;
 
     // A stream transforms the F frames [m0, m0+F), m0 = m_lo - 1 + stream * F, and nothing else: no halo
     // frames are recomputed.  Frames come in pairs (a, b) = (odd j, j+1) so that one inverse FFT returns the
@@ -407,12 +459,14 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     const int n_iter = F / 2;
 
     cf* const tw = lds_all + C::G * C::PITCH;   // LDS twiddle table, after the stream buffers
+    const cf* const bigtw = tw + SC::TW_CF;     // wide: W_N^(k1 n2), row k1 at k1 * BT_ROW
 
     // ---- copy the twiddle table into LDS ------------------------------------
     ex.each([&](int tid, Thread&) {
         const UPX_GLOBAL cf* src = opaque(a.tw);
         for (int i = tid; i < C::TW_CF; i += C::WG) tw[i] = src[i];
     });
+    if constexpr (WIDE) ex.wg_barrier();
 
     // ---- pieces (per thread) ------------------------------------------------
     // Frame j of a stream covers samples j HOP + lane + s LANES.  Slots s < P-HS were part of the
@@ -467,9 +521,41 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #endif
             th.x[s] = mk(v.x * w, v.y * w);
         }
-        S::template pass_compute<0>(th, tw, lane);
+        if constexpr (WIDE) {
+            // radix-16 over n1 in registers, then W_N^(k1 n2) (n2 = tid)
+            Dft<16>::run(th.x);
+            const cf* bt = bigtw + tid;
+#pragma unroll
+            for (int r = 1; r < P; ++r) th.x[r] = cmul(th.x[r], lds_load(bt + r * C::BT_ROW));
+        } else {
+            S::template pass_compute<0>(th, tw, lane);
+        }
         UPX_SCHED_FENCE();   // keep the prefetch behind the loads this frame waits for (vmcnt retires in order)
         prefetch(tid, th, it + (half == 1 ? 1 : 0), half == 1 ? 0 : 1);
+    };
+    // last step of an inverse transform: time samples lane + s LANES land in slot s
+    auto final_pass = [&](int tid, Thread& th) {
+        if constexpr (WIDE) {
+            // column n2 = tid of the sixteen sub-FFT buffers, radix-16 over k1
+            const cf* b = lds_all + padp<P>(tid);
+#pragma unroll
+            for (int r = 0; r < P; ++r) th.x[r] = lds_load(b + wide_sub_of_k1(r) * BUF);
+            Dft<16>::run(th.x);
+        } else {
+            S::read_all(th, lds_all + (tid / SL) * BUF, tid % SL);
+            S::template pass_compute<LAST>(th, tw, tid % SL);
+        }
+    };
+    // first exchange of a forward transform
+    auto head_write = [&](int tid, Thread& th) {
+        if constexpr (WIDE) {
+            // transposed: value k1 of lane n2 goes to element n2 of sub-FFT g(k1) - the same cells final_pass reads
+            cf* b = lds_all + padp<P>(tid);
+#pragma unroll
+            for (int r = 0; r < P; ++r) b[wide_sub_of_k1(r) * BUF] = th.x[r];
+        } else {
+            S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL);
+        }
     };
     // read-modify-write of one emitted hop: the old values are fetched BEFORE the final pass
     // so that their HBM latency overlaps the butterflies
@@ -503,8 +589,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #else
         for (int s = 0; s < P; ++s) w[s] = opaque(w_s + s * LANES)[lane];
 #endif
-        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
-        S::template pass_compute<LAST>(th, tw, lane);
+        final_pass(tid, th);
 #pragma unroll
         for (int s = 0; s < P; ++s) {
             th.acc_l[s] += th.x[s].y * w[s];   // swapped output: Re y = x.y, Im y = x.x
@@ -558,8 +643,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #else
         for (int s = 0; s < P; ++s) w[s] = opaque(w_s + s * LANES)[lane];
 #endif
-        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, lane);
-        S::template pass_compute<LAST>(th, tw, lane);
+        final_pass(tid, th);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int j = ja + half;
@@ -581,25 +665,55 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
         }
     };
-    // split L/R, gain, mask, build the iFFT input.  Partners Z[N-k] are read from the upper
-    // region [N/2, N); the mirrored bins Y[N-k] go to the (free) lower region at position
-    // (N-k) - N/2, position 0 = Nyquist (lane 0).
+    // Where the mirror bins live.  Own bins k (slots s < H) stay in registers; the partner Z[N-k_s] is read
+    // from `zpart + (H-1-s) SP` and the mirrored output Y[N-k_s] is written to `ymir + (H-1-s) SP`, where the
+    // first inverse pass picks it up as an upper slot.
+    //   plain: partners are parked in the upper region [N/2, N); mirrors go to the (free) lower region at
+    //          position (N-k) - N/2, position 0 = Nyquist (lane 0).
+    //   wide:  bin k = k1 + 16 k2 of sub-FFT g pairs with k2' = N2 - (k1 != 0) - k2 of sub-FFT g^1 (g itself for
+    //          k1 = 0, 8): an upper slot of a lane in the same wave, rewritten in place.
+    struct Mirror {
+        cf* zpart;
+        cf* ymir;
+        cf* nyq;      // where the Nyquist bin of the inverse input goes
+        bool first;   // this lane holds DC (slot 0) and Nyquist (slot H)
+    };
+    auto mirror_of = [&](int tid) {
+        Mirror m;
+        const int sl = tid % SL;
+        if constexpr (WIDE) {
+            const int g = tid / SL;
+            const int gp = (g >> 1) ? (g ^ 1) : g;
+            const int z = wide_k1_of_sub(g) ? 1 : 0;
+            m.zpart = m.ymir = lds_all + gp * BUF + padp<P>((H + 1) * SL - z - sl);
+            m.nyq = lds_all + H * SP;
+            m.first = tid == 0;
+        } else {
+            cf* lds = lds_all + (tid / SL) * BUF;
+            m.zpart = lds + padp<P>(N - sl - (H - 1) * LANES);
+            m.ymir = lds + padp<P>(N / 2 - sl - (H - 1) * LANES);
+            m.nyq = lds;
+            m.first = sl == 0;
+        }
+        return m;
+    };
+    // split L/R, gain, mask, build the iFFT input
     auto mask = [&](int tid, Thread& th, int half) {
         const int lane = tid % LANES;
-        cf* lds = lds_all + (tid / LANES) * C::PITCH;
+        const Mirror mir = mirror_of(tid);
         const UPX_GLOBAL float* gain = opaque(a.gain);
-        // k_s = lane + s LANES:  padp(N - k_s) = padp(N - lane - (H-1) LANES) + (H-1-s) SP
-        const cf* zpart = lds + padp<P>(N - lane - (H - 1) * LANES);
-        cf* ymir = lds + padp<P>(N / 2 - lane - (H - 1) * LANES);
         cf nyq_y = mk(0.f, 0.f);
         float nyq_c = 0.f;
         const int n_gain = a.n_gain, gstride = a.gain_stride;
-        if (lane == 0) {
+        float g1[H];
+#pragma unroll
+        for (int s = 0; s < H; ++s) g1[s] = n_gain > 1 ? opaque(gain + s * LANES)[gstride + lane] : 0.f;
+        if (mir.first) {
             // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
             const cf z = th.x[H];
             cf cn = mk(0.f, 0.f), lsn = cn, rsn = cn;
             for (int q = 0; q < n_gain; ++q) {
-                const float g2 = gain[q * gstride + N / 2];
+                const float g2 = q < 2 ? th.gn[q] : gain[q * gstride + N / 2];
                 if (g2 != 0.f) {
                     cf l = mk(g2 * (z.x + z.x), 0.f), r = mk(g2 * (z.y + z.y), 0.f), c, ls, rs;
                     mask_bin(l, r, c, ls, rs);
@@ -609,39 +723,47 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             nyq_y = mk(lsn.x, rsn.x);
             nyq_c = cn.x;
         }
+        // all partners first: one LDS round trip instead of one per bin (the mirror writes below may alias them
+        // as far as the compiler can tell, so it would not hoist the reads itself)
+        cf zpart[H];
+#pragma unroll
+        for (int s = 0; s < H; ++s) zpart[s] = lds_load(mir.zpart + (H - 1 - s) * SP);   // k == 0: spare row, unused
 #pragma unroll
         for (int s = 0; s < H; ++s) {
-            const bool dc = s == 0 && lane == 0;   // k == 0
+            const bool dc = s == 0 && mir.first;   // k == 0
             const cf za = th.x[s];
-            const cf zp = lds_load(zpart + (H - 1 - s) * SP);   // for k == 0 this is index N (spare row), unused
-            const cf zb = dc ? za : zp;              // DC pairs with itself
+            const cf zb = dc ? za : zpart[s];        // DC pairs with itself
             const cf l0 = mk(za.x + zb.x, za.y - zb.y);   // Z[k] + conj Z[N-k]        (x gain/2 = L)
             const cf r0 = mk(za.y + zb.y, zb.x - za.x);   // (Z[k] - conj Z[N-k]) / i  (x gain/2 = R)
             cf c = mk(0.f, 0.f), ls = c, rs = c;
-            const UPX_GLOBAL float* gp = opaque(gain + s * LANES) + lane;
-            for (int q = 0; q < n_gain; ++q) {
-#if defined(UPX_EXP) && UPX_EXP >= 3
-                const float g2 = 0.5f;
-#else
-                const float g2 = gp[q * gstride];
-#endif
-                if (g2 != 0.f) {
+            auto add_band = [&](float g2) {
+                if (g2 != 0.f) {   // whole waves lie outside the band: the branch skips them
                     cf l = mk(g2 * l0.x, g2 * l0.y), r = mk(g2 * r0.x, g2 * r0.y), cq, lq, rq;
                     mask_bin(l, r, cq, lq, rq);
                     c = c + cq; ls = ls + lq; rs = rs + rq;
                 }
+            };
+            // Gain slot 0 was fetched during the previous phase, slot 1 at the top of this one: a load issued
+            // here exposes one L2 round trip per bin, eight in a row.  Further slots (three or more merged
+            // bands overlapping in one bin) are rare and take that path.
+            // plain: bin lane + s LANES.  wide: the table is stored in the kernel's bin order (gain_bin)
+            add_band(th.g0[s]);
+            if (n_gain > 1) {
+                add_band(g1[s]);
+                const UPX_GLOBAL float* gp = opaque(gain + s * LANES) + lane;
+                for (int q = 2; q < n_gain; ++q) add_band(gp[q * gstride]);
             }
             // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
             const cf yk = mk(ls.x - rs.y, ls.y + rs.x);
             const cf ym = mk(ls.x + rs.y, rs.x - ls.y);
             th.x[s] = cswap(yk);
             if (s == 0) {
-                cf* dst = lane == 0 ? lds : ymir + (H - 1) * SP;   // lane 0: Nyquist at position 0
-                *dst = cswap(lane == 0 ? nyq_y : ym);
+                cf* dst = mir.first ? mir.nyq : mir.ymir + (H - 1) * SP;
+                *dst = cswap(mir.first ? nyq_y : ym);
             } else {
-                ymir[(H - 1 - s) * SP] = cswap(ym);
+                mir.ymir[(H - 1 - s) * SP] = cswap(ym);
             }
-            // centre spectrum; lane 0 slot 0 packs the two real bins (DC, Nyquist)
+            // centre spectrum; the first lane's slot 0 packs the two real bins (DC, Nyquist)
             const cf cv = dc ? mk(c.x, nyq_c) : c;
             if (half == 0) {
                 th.cs[s] = cv;
@@ -659,49 +781,79 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             }
         }
     };
-    // first inverse pass: slots >= H hold Y[lane + s LANES], parked at position idx - N/2
+    // first inverse pass: slots >= H hold the mirrored bins (plain: parked at position idx - N/2; wide: in place)
     auto inv0 = [&](int tid, Thread& th) {
-        const int lane = tid % LANES;
-        const cf* b = lds_all + (tid / LANES) * C::PITCH + padp<P>(lane);
+        const int sl = tid % SL;
+        const cf* b = lds_all + (tid / SL) * BUF + padp<P>(sl);
 #pragma unroll
-        for (int s = H; s < P; ++s) th.x[s] = lds_load(b + (s - H) * SP);
-        S::template pass_compute<0>(th, tw, lane);
+        for (int s = H; s < P; ++s) th.x[s] = lds_load(b + (WIDE ? s : s - H) * SP);
+        S::template pass_compute<0>(th, tw, sl);
     };
-    auto scatter0 = [&](int tid, Thread& th) {
-        S::template pass_write<0>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES);
-    };
+    auto scatter0 = [&](int tid, Thread& th) { S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL); };
     auto mids = [&]() { S::template mid_passes<1>(ex, lds_all, tw); };
     auto zsplit_compute = [&](int tid, Thread& th) {
-        S::read_all(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES);
-        S::template pass_compute<LAST>(th, tw, tid % LANES);
+        const UPX_GLOBAL float* gain = opaque(a.gain);
+#pragma unroll
+        for (int s = 0; s < H; ++s) th.g0[s] = opaque(gain + s * LANES)[tid % LANES];
+        th.gn[0] = gain[N / 2];
+        th.gn[1] = a.n_gain > 1 ? gain[a.gain_stride + N / 2] : 0.f;
+        S::read_all(th, lds_all + (tid / SL) * BUF, tid % SL);
+        S::template pass_compute<LAST>(th, tw, tid % SL);
     };
     auto zsplit_write = [&](int tid, Thread& th) {
-        cf* b = lds_all + (tid / LANES) * C::PITCH + padp<P>(tid % LANES);
+        cf* b = lds_all + (tid / SL) * BUF + padp<P>(tid % SL);
 #pragma unroll
         for (int s = H; s < P; ++s) b[s * SP] = th.x[s];
     };
     auto stage_c = [&](int tid, Thread& th) {
-        const int lane = tid % LANES;
-        cf* lds = lds_all + (tid / LANES) * C::PITCH;
-        cf* ymir = lds + padp<P>(N / 2 - lane - (H - 1) * LANES);
+        const Mirror mir = mirror_of(tid);
 #pragma unroll
         for (int s = 0; s < H; ++s) {
             th.x[s] = th.cs[s];
             if (s == 0) {
-                cf* dst = lane == 0 ? lds : ymir + (H - 1) * SP;
+                cf* dst = mir.first ? mir.nyq : mir.ymir + (H - 1) * SP;
                 *dst = th.part[0];
             } else {
-                ymir[(H - 1 - s) * SP] = th.part[s];
+                mir.ymir[(H - 1 - s) * SP] = th.part[s];
             }
         }
     };
-    // forward transform from the scattered pass 0 to the iFFT input, then the inverse passes
+    // wide only: first pass of a sub-FFT, and the end of an inverse sub-FFT (last pass, * W_N^(k1 n2), back
+    // into the own buffer, from where final_pass reads columns after the barrier)
+    auto sub_first = [&](int tid, Thread& th) {
+        S::read_all(th, lds_all + (tid / SL) * BUF, tid % SL);
+        S::template pass_compute<0>(th, tw, tid % SL);
+    };
+    auto sub_last_inv = [&](int tid, Thread& th) {
+        if constexpr (WIDE) {
+            const int g = tid / SL, sl = tid % SL;
+            cf* b = lds_all + g * BUF + padp<P>(sl);
+            S::read_all(th, lds_all + g * BUF, sl);
+            S::template pass_compute<LAST>(th, tw, sl);
+            const cf* bt = bigtw + wide_k1_of_sub(g) * C::BT_ROW + sl;   // row 0 is all ones
+#pragma unroll
+            for (int s = 0; s < P; ++s) b[s * SP] = cmul(th.x[s], lds_load(bt + s * SL));
+        }
+    };
+    // inverse transform from the staged input (own slots in registers, mirrors in LDS) up to the final pass
+    auto inverse_body = [&]() {
+        ex.each2(inv0, scatter0);
+        mids();
+        if constexpr (WIDE) {
+            ex.each(sub_last_inv);
+            ex.wg_barrier();   // columns complete: final_pass may read across waves
+        }
+    };
+    // forward transform from the first exchange to the iFFT input, then the inverse passes
     auto frame_body = [&](int half) {
+        if constexpr (WIDE) {
+            ex.wg_barrier();   // transposed writes of head_write complete
+            ex.each2(sub_first, scatter0);
+        }
         mids();
         ex.each2(zsplit_compute, zsplit_write);
         ex.each([&](int tid, Thread& th) { mask(tid, th, half); });
-        ex.each2(inv0, scatter0);
-        mids();
+        inverse_body();
     };
 
     ex.each([&](int tid, Thread& th) {
@@ -713,14 +865,17 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // One extra trip runs only the centre tail of the last pair.  tail_c is instantiated ONCE
     // (inside this loop) on purpose: two inlined copies may contract multiply-adds differently,
     // and which copy a frame meets would then depend on how the signal is cut into streams.
-    for (int it = 0; it <= n_iter; ++it) {
+    // Wide streams: `each` orders one wave only; the cross-wave phases (final_pass reads, head_write writes)
+    // touch lane-private cells, so they need barriers only against the wave-local phases around them.
+    int it = 0;   // outlives the loop: the host emulator of wide streams runs recorded phases at the next barrier
+    for (; it <= n_iter; ++it) {
         ex.each2(
             [&](int tid, Thread& th) {
                 if (it > 0) tail_c(tid, th, it - 1);
                 if (it < n_iter) head(tid, th, it, 0);
             },
             [&](int tid, Thread& th) {
-                if (it < n_iter) scatter0(tid, th);
+                if (it < n_iter) head_write(tid, th);
             });
         if (it == n_iter) break;
         frame_body(0);
@@ -729,11 +884,16 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
                 tail_lr(tid, th, it, 0);
                 head(tid, th, it, 1);
             },
-            scatter0);
+            head_write);
         frame_body(1);
-        ex.each2([&](int tid, Thread& th) { tail_lr(tid, th, it, 1); }, stage_c);
-        ex.each2(inv0, scatter0);
-        mids();
+        if constexpr (WIDE) {
+            ex.each([&](int tid, Thread& th) { tail_lr(tid, th, it, 1); });
+            ex.wg_barrier();   // every wave has read its columns before the centre pair is staged over them
+            ex.each(stage_c);
+        } else {
+            ex.each2([&](int tid, Thread& th) { tail_lr(tid, th, it, 1); }, stage_c);
+        }
+        inverse_body();
     }
     // what is left in the accumulators belongs to the K-1 blocks after this stream
     ex.each([&](int tid, Thread& th) {
@@ -747,6 +907,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             seam[(2 * (P - HS) + s) * LANES] = th.acc_r[s];
         }
     });
+    if constexpr (WIDE) ex.wg_barrier();
 }
 
 // Adds the tail of stream `sid` onto the first blocks of stream sid+1; one call per (sid, i), i < (K-1) hop.
@@ -777,6 +938,35 @@ inline void fill_twiddles(cf* tw, TrigFn trig) {
                 trig((double)r * (double)k / ((double)NS * (double)R), c, s);   // fraction of a turn
                 tw[off + (r - 1) * NS + k] = mk((float)c, (float)-s);
             }
+    }
+}
+
+// Twiddle table of a kernel configuration: the (sub-)FFT passes, then for wide streams W_N^(k1 n2).
+template <class C, class TrigFn>
+inline void fill_tables(cf* tw, TrigFn trig) {
+    fill_twiddles<typename C::Sub>(tw, trig);
+    if constexpr (C::WIDE) {
+        cf* bt = tw + C::Sub::TW_CF;
+        for (int k1 = 0; k1 < 16; ++k1)
+            for (int n2 = 0; n2 < C::BT_ROW; ++n2) {
+                double c, s;
+                trig((double)k1 * (double)n2 / (double)C::N, c, s);
+                bt[k1 * C::BT_ROW + n2] = mk((float)c, (float)-s);
+            }
+    }
+}
+
+// Order of the per-bin gain rows as the kernel reads them: entry i = s * LANES + tid (s < P/2) is the bin that
+// slot s of thread tid owns, entry N/2 the Nyquist bin.  Plain streams: the natural order.
+template <class C>
+inline int gain_bin(int i) {
+    if constexpr (C::WIDE) {
+        if (i >= C::N / 2) return i;
+        const int s = i / C::LANES, tid = i % C::LANES;
+        const int g = tid / C::Sub::LANES, sl = tid % C::Sub::LANES;
+        return wide_k1_of_sub(g) + 16 * (sl + C::Sub::LANES * s);
+    } else {
+        return i;
     }
 }
 

@@ -73,6 +73,12 @@ struct DevExec {
         }
 #endif
     }
+    // Wide streams run their phases with wave-level ordering (WAVE_SYNC) and meet here.
+    __device__ __forceinline__ void wg_barrier() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
     template <class F>
     __device__ __forceinline__ void each(F&& f) {
         f((int)threadIdx.x, st);
@@ -93,7 +99,7 @@ struct DevExec {
 template <class C, int WPE>
 __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<C::WAVE_SYNC, C::P> ex;
+    DevExec<C::WAVE_SYNC || C::WIDE, C::P> ex;
     upx::band_program<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 
@@ -228,6 +234,8 @@ struct KernelEntry {
     int wg, g, lds_bytes, tw_cf, lanes, wpe;
     void (*fill_tw)(upx::cf*);
     const char* name;
+    int (*gain_bin)(int);   // order of the per-bin gain rows as the kernel reads them
+    int layout;             // distinguishes twiddle table layouts of one STFT size
 };
 
 void turn_trig(double frac, double& c, double& s) {
@@ -300,15 +308,18 @@ struct Entry {
         return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_band_kernel<C, WPE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     }
-    static void fill(upx::cf* tw) { upx::fill_twiddles<C>(tw, turn_trig); }
+    static void fill(upx::cf* tw) { upx::fill_tables<C>(tw, turn_trig); }
     static KernelEntry get(const char* name) {
-        return KernelEntry{&launch, &prepare, C::WG, C::G, kLds, C::TW_CF, C::LANES, WPE, &fill, name};
+        return KernelEntry{&launch, &prepare, C::WG, C::G, kLds, C::TW_CF, C::LANES, WPE, &fill, name,
+                           &upx::gain_bin<C>, C::WIDE ? 1000 : C::LANES};
     }
 };
 
 // (log2 N, K, variant) -> kernel.  K = N / hop.
-//   variant 0: 16 points per lane, register budget for 2 waves/SIMD (256 VGPRs)
+//   variant 0: 16 points per lane, register budget for 2 waves/SIMD (256 VGPRs); N = 4096 / 8192 as wide
+//              streams (one workgroup barrier per transform, upx::WideCfg)
 //   variant 1:  8 points per lane, register budget for 4 waves/SIMD (128 VGPRs)
+//   variant 2: 16 points per lane, plain Stockham schedule for every size
 // UPX_KERNEL_VARIANT selects; the default is set in default_variant().
 const KernelEntry* find_kernel(int log2n, int k, int variant) {
     static const std::map<std::tuple<int, int, int>, KernelEntry> table = [] {
@@ -318,8 +329,16 @@ const KernelEntry* find_kernel(int log2n, int k, int variant) {
 #define UPX_REG_SIZES(K, PP, W, V) \
     UPX_REG(8, K, PP, W, V) UPX_REG(9, K, PP, W, V) UPX_REG(10, K, PP, W, V) UPX_REG(11, K, PP, W, V) \
     UPX_REG(12, K, PP, W, V) UPX_REG(13, K, PP, W, V)
-        UPX_REG_SIZES(2, 16, 2, 0) UPX_REG_SIZES(4, 16, 2, 0) UPX_REG_SIZES(8, 16, 2, 0)
+#define UPX_REG_SMALL(K, PP, W, V) \
+    UPX_REG(8, K, PP, W, V) UPX_REG(9, K, PP, W, V) UPX_REG(10, K, PP, W, V) UPX_REG(11, K, PP, W, V)
+#define UPX_REG_WIDE(L, K) \
+    t[std::make_tuple(L, K, 0)] = Entry<upx::WideCfg<L, K>, 2>::get("upx_band_kernel<WideCfg<" #L "," #K ">,2>");
+        UPX_REG_SMALL(2, 16, 2, 0) UPX_REG_SMALL(4, 16, 2, 0) UPX_REG_SMALL(8, 16, 2, 0)
+        UPX_REG_WIDE(12, 2) UPX_REG_WIDE(12, 4) UPX_REG_WIDE(12, 8) UPX_REG_WIDE(13, 2) UPX_REG_WIDE(13, 4) UPX_REG_WIDE(13, 8)
         UPX_REG_SIZES(2, 8, 4, 1) UPX_REG_SIZES(4, 8, 4, 1) UPX_REG_SIZES(8, 8, 4, 1)
+        UPX_REG_SIZES(2, 16, 2, 2) UPX_REG_SIZES(4, 16, 2, 2) UPX_REG_SIZES(8, 16, 2, 2)
+#undef UPX_REG_WIDE
+#undef UPX_REG_SMALL
 #undef UPX_REG_SIZES
 #undef UPX_REG
         return t;
@@ -520,7 +539,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         HIP_TRY(hipMemcpy(s.d_wa, w_analysis + off_w, s.n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.d_ws, ws.data(), s.n * sizeof(float), hipMemcpyHostToDevice));
         band_gain_off.push_back(off_g);
-        const int tw_key = s.log2n * 100000 + (s.kern ? s.kern->lanes : 0);   // layout depends on points per lane
+        const int tw_key = s.log2n * 100000 + (s.kern ? s.kern->layout : 0);   // layout depends on the kernel flavour
         auto it = p->tw.find(tw_key);
         if (it == p->tw.end()) {
             const size_t cnt = (size_t)(s.kern ? s.kern->tw_cf : s.big->row_tw_cf);
@@ -567,6 +586,12 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                 const float g = gain[band_gain_off[m] + k];
                 if (g != 0.f) table[(size_t)count[k]++ * nb + k] = 0.5f * g;
             }
+        if (s.kern) {
+            // rows in the order the kernel's threads read them (natural for plain streams)
+            std::vector<float> natural(table);
+            for (int q = 0; q < slots; ++q)
+                for (int i = 0; i < nb; ++i) table[(size_t)q * nb + i] = natural[(size_t)q * nb + s.kern->gain_bin(i)];
+        }
         s.n_gain = slots;
         HIP_TRY(hipMalloc(&s.d_gain, table.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(s.d_gain, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
