@@ -29,16 +29,66 @@
 
 namespace upx {
 
+// One complex float.  Under clang (device AND host pass of hipcc, so that kernel signatures agree) it is a
+// 2-vector: a complex add is then ONE v_pk_add_f32 and the products below ONE or TWO packed instructions.  A wave
+// issues a packed f32 instruction about as fast as a scalar one, and at two waves per SIMD the kernel is bound by
+// each wave's own issue stream, so halving the instruction count of the butterflies is what pays.  Other
+// compilers (the g++ build of the host emulator) see a plain struct with the same layout and scalar arithmetic.
+#if defined(__clang__)
+typedef float cf __attribute__((ext_vector_type(2)));
+#else
 struct cf {
     float x, y;
 };
+UPX_HD cf operator+(cf a, cf b) { cf r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
+UPX_HD cf operator-(cf a, cf b) { cf r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
+#endif
 
 UPX_HD cf mk(float a, float b) { cf r; r.x = a; r.y = b; return r; }
-UPX_HD cf operator+(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
-UPX_HD cf operator-(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-UPX_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-UPX_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }   // a * (-i)
 UPX_HD cf cswap(cf a) { return mk(a.y, a.x); }
+UPX_HD cf scale(cf a, float s) {
+#if defined(__clang__)
+    return a * s;
+#else
+    return mk(a.x * s, a.y * s);
+#endif
+}
+UPX_HD cf mul_mi(cf a) { return mk(a.y, -a.x); }   // a * (-i)
+
+// The sign / swap patterns of complex arithmetic as single packed instructions (VOP3P op_sel picks the source
+// half per result half, neg_lo / neg_hi flip a source per result half); the host forms define the meaning.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UPX_PK2(name, text)                                       \
+    UPX_HD cf name(cf a, cf b) {                                  \
+        cf t;                                                     \
+        asm(text : "=v"(t) : "v"(a), "v"(b));                     \
+        return t;                                                 \
+    }
+// a b: (ax bx - ay by, ax by + ay bx)
+UPX_HD cf cmul(cf a, cf b) {
+    cf t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(t)
+        : "v"(a), "v"(b));
+    return t;
+}
+UPX_PK2(add_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")        // a - i b
+UPX_PK2(sub_mi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")        // a + i b
+UPX_PK2(add_conj, "v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1] neg_hi:[0,1]")                                   // a + conj b
+UPX_PK2(mi_sub_conj, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]")   // -i (a - conj b)
+UPX_PK2(swap_add_i, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[0,1]")    // swap(a + i b)
+UPX_PK2(swap_conj_add_i, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]")   // swap(conj a + i conj b)
+#undef UPX_PK2
+#else
+UPX_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+UPX_HD cf add_mi(cf a, cf b) { return mk(a.x + b.y, a.y - b.x); }
+UPX_HD cf sub_mi(cf a, cf b) { return mk(a.x - b.y, a.y + b.x); }
+UPX_HD cf add_conj(cf a, cf b) { return mk(a.x + b.x, a.y - b.y); }
+UPX_HD cf mi_sub_conj(cf a, cf b) { return mk(a.y + b.y, b.x - a.x); }
+UPX_HD cf swap_add_i(cf a, cf b) { return mk(a.y + b.x, a.x - b.y); }
+UPX_HD cf swap_conj_add_i(cf a, cf b) { return mk(b.x - a.y, a.x + b.y); }
+#endif
 
 UPX_HD float fast_rcp(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -119,16 +169,24 @@ UPX_HD void dft2(cf& a, cf& b) {
 }
 
 UPX_HD void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
-    cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi(a1 - a3);
+    cf t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
     a0 = t0 + t2;
     a2 = t0 - t2;
-    a1 = t1 + t3;
-    a3 = t1 - t3;
+    a1 = add_mi(t1, d);
+    a3 = sub_mi(t1, d);
+}
+// the same with input a2 still to be multiplied by -i
+UPX_HD void dft4_mi2(cf& a0, cf& a1, cf& a2, cf& a3) {
+    cf t0 = add_mi(a0, a2), t1 = sub_mi(a0, a2), t2 = a1 + a3, d = a1 - a3;
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = add_mi(t1, d);
+    a3 = sub_mi(t1, d);
 }
 
 // multiply by W8^1 = (1 - i)/sqrt2 and W8^3 = (-1 - i)/sqrt2
-UPX_HD cf mul_w8_1(cf a) { return mk((a.x + a.y) * kSqrtHalf, (a.y - a.x) * kSqrtHalf); }
-UPX_HD cf mul_w8_3(cf a) { return mk((a.y - a.x) * kSqrtHalf, -(a.x + a.y) * kSqrtHalf); }
+UPX_HD cf mul_w8_1(cf a) { return scale(add_mi(a, a), kSqrtHalf); }    // (x + y, y - x) / sqrt2
+UPX_HD cf mul_w8_3(cf a) { return scale(sub_mi(a, a), -kSqrtHalf); }   // -(x - y, y + x) / sqrt2
 
 template <int R>
 struct Dft;
@@ -150,11 +208,10 @@ struct Dft<8> {
         dft4(e0, e1, e2, e3);
         dft4(o0, o1, o2, o3);
         o1 = mul_w8_1(o1);
-        o2 = mul_mi(o2);
         o3 = mul_w8_3(o3);
         v[0] = e0 + o0; v[4] = e0 - o0;
         v[1] = e1 + o1; v[5] = e1 - o1;
-        v[2] = e2 + o2; v[6] = e2 - o2;
+        v[2] = add_mi(e2, o2); v[6] = sub_mi(e2, o2);   // o2 * (-i)
         v[3] = e3 + o3; v[7] = e3 - o3;
     }
 };
@@ -173,14 +230,14 @@ struct Dft<16> {
         y[1][2] = mul_w8_1(y[1][2]);
         y[1][3] = cmul(y[1][3], w3);
         y[2][1] = mul_w8_1(y[2][1]);
-        y[2][2] = mul_mi(y[2][2]);
-        y[2][3] = mul_w8_3(y[2][3]);
+        y[2][3] = mul_w8_3(y[2][3]);   // y[2][2] * (-i) happens inside dft4_mi2
         y[3][1] = cmul(y[3][1], w3);
         y[3][2] = mul_w8_3(y[3][2]);
         y[3][3] = cmul(y[3][3], mk(-kC16, kS16));   // W16^9 = -W16^1
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) {
-            dft4(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
+            if (k1 == 2) dft4_mi2(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
+            else dft4(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
             v[k1] = y[0][k1]; v[k1 + 4] = y[1][k1]; v[k1 + 8] = y[2][k1]; v[k1 + 12] = y[3][k1];
         }
     }
@@ -328,7 +385,7 @@ UPX_HD void mask_bin(cf l, cf r, cf& c, cf& ls, cf& rs) {
     float coh = p * fast_rcp(p + kEps);
     float bal = (ml - mr) * fast_rcp(ml + mr + kEps);
     float h = 0.5f * coh * (1.0f - __builtin_fabsf(bal));
-    c = mk(h * (l.x + r.x), h * (l.y + r.y));
+    c = scale(l + r, h);
     ls = l - c;
     rs = r - c;
 }
@@ -337,8 +394,7 @@ UPX_HD void mask_bin(cf l, cf r, cf& c, cf& ls, cf& rs) {
 template <int P>
 struct ThreadT {
     cf x[P];          // FFT working set
-    float acc_l[P];   // overlap-add state, slot s <-> sample lane + s*LANES of the current frame
-    float acc_r[P];
+    cf acc_rl[P];     // overlap-add state of (Rs, Ls), slot s <-> sample lane + s*LANES of the current frame
     float acc_c[P];
     cf cs[P / 2];     // centre spectrum of the pair: C_a, then Yc[k]
     cf part[P / 2];   // Yc[N-k] of the pair
@@ -398,6 +454,39 @@ struct Stream {
 #pragma unroll
         for (int s = 0; s < P; ++s) th.x[s] = lds_load(b + s * C::SPITCH);
     }
+    // read_all + pass_compute<PI>.  For a radix-P pass all 2P-1 LDS reads (inputs and twiddles) are issued
+    // before the first multiply, in the order the butterfly consumes them (its first radix-4 takes inputs 0, 4, 8,
+    // 12): left to itself the scheduler splits them into three batches and waits for each to come back in
+    // full - three exposed LDS round trips per pass instead of one.
+    template <int PI>
+    static UPX_HD void read_compute(Thread& th, const cf* lds, const cf* tw, int lane) {
+        constexpr int R = PS::r[PI];
+        constexpr int NS = pass_ns(PS::r, PI);
+        if constexpr (R == P && P == 16) {
+            constexpr int OFF = tw_offset(PS::r, PI);
+            const cf* b = lds + padp<P>(lane);
+            const cf* row = tw + OFF + (lane & (NS - 1));
+            cf w[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int r = (i & 3) * 4 + (i >> 2);   // 0 4 8 12 1 5 9 13 ...
+                th.x[r] = lds_load(b + r * C::SPITCH);
+                if (NS > 1 && r > 0) w[r] = lds_load(row + (r - 1) * NS);
+            }
+            UPX_SCHED_FENCE();
+            if (NS > 1) {
+#pragma unroll
+                for (int i = 1; i < P; ++i) {
+                    const int r = (i & 3) * 4 + (i >> 2);
+                    th.x[r] = cmul(th.x[r], w[r]);
+                }
+            }
+            Dft<P>::run(th.x);
+        } else {
+            read_all(th, lds, lane);
+            pass_compute<PI>(th, tw, lane);
+        }
+    }
 
     // passes PI..n-2:  [read, transform] | [scatter] |   ('|' = barrier)
     template <int PI, class Ex>
@@ -407,10 +496,7 @@ struct Stream {
             // between; a stream inside ONE wave does not (LDS operations of a wave execute in order and every
             // scattered value depends on all 16 values read), so its executor runs f and g back to back.
             ex.each2(
-                [&](int tid, Thread& th) {
-                    read_all(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES);
-                    pass_compute<PI>(th, tw, tid % LANES);
-                },
+                [&](int tid, Thread& th) { read_compute<PI>(th, lds_all + (tid / LANES) * C::PITCH, tw, tid % LANES); },
                 [&](int tid, Thread& th) { pass_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
             mid_passes<PI + 1>(ex, lds_all, tw);
         }
@@ -494,7 +580,14 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #endif
         }
     };
-    auto head = [&](int tid, Thread& th, int it, int half) {
+    // The samples a frame shares with its predecessor (L2 hits) and the analysis window.  Issued at the TOP of the
+    // phase that ends the previous inverse transform: behind that phase's stores the compiler could not hoist
+    // them itself (it cannot tell the planes from the input), and a whole L2 round trip would be exposed.
+    struct HeadRegs {
+        cf v[P];      // first P-HS used
+        float w[P];
+    };
+    auto head_fetch = [&](int tid, int it, int half, HeadRegs& hr) {
         const int lane = tid % LANES;
         bool exists;
         const int j = frame_of(tid, it, half, exists);
@@ -503,23 +596,38 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const UPX_GLOBAL float* w_a = opaque(a.w_a);
         const int last = a.t_in - 1;   // host guarantees t_in >= 1
 #pragma unroll
-        for (int s = 0; s < P; ++s) {
-            // always load an in-range sample, then zero what lies past the signal or in a
-            // frame this stream does not own (zero-extension of center_extraction.py:437-455)
+        for (int s = 0; s < P - HS; ++s) {
+            // always load an in-range sample; head() zeroes what lies past the signal or in a frame this
+            // stream does not own (zero-extension of center_extraction.py:437-455)
             const int n = e + s * LANES;
-            cf v;
 #if defined(UPX_EXP) && UPX_EXP >= 4
-            if (s < P - HS) v = mk(0.01f * (n & 7), 0.02f);
+            hr.v[s] = mk(0.01f * (n & 7), 0.02f);
 #else
-            if (s < P - HS) v = in[n < last ? n : last];
+            hr.v[s] = in[n < last ? n : last];
 #endif
-            else v = th.pre[s - (P - HS)];
+        }
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
 #if defined(UPX_EXP) && UPX_EXP >= 3
-            const float w = (exists && n <= last) ? 0.5f : 0.f;
+            hr.w[s] = 0.5f;
 #else
-            const float w = (exists && n <= last) ? opaque(w_a + s * LANES)[lane] : 0.f;
+            hr.w[s] = opaque(w_a + s * LANES)[lane];
 #endif
-            th.x[s] = mk(v.x * w, v.y * w);
+        }
+        UPX_SCHED_FENCE();
+    };
+    auto head = [&](int tid, Thread& th, int it, int half, const HeadRegs& hr) {
+        const int lane = tid % LANES;
+        bool exists;
+        const int j = frame_of(tid, it, half, exists);
+        const int e = exists ? j * HOP + lane : 0;
+        const int last = a.t_in - 1;
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            const int n = e + s * LANES;
+            const cf v = s < P - HS ? hr.v[s] : th.pre[s < P - HS ? 0 : s - (P - HS)];
+            const float w = (exists && n <= last) ? hr.w[s] : 0.f;
+            th.x[s] = scale(v, w);
         }
         if constexpr (WIDE) {
             // radix-16 over n1 in registers, then W_N^(k1 n2) (n2 = tid)
@@ -542,8 +650,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             for (int r = 0; r < P; ++r) th.x[r] = lds_load(b + wide_sub_of_k1(r) * BUF);
             Dft<16>::run(th.x);
         } else {
-            S::read_all(th, lds_all + (tid / SL) * BUF, tid % SL);
-            S::template pass_compute<LAST>(th, tw, tid % SL);
+            S::template read_compute<LAST>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
         }
     };
     // first exchange of a forward transform
@@ -592,25 +699,23 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         final_pass(tid, th);
 #pragma unroll
         for (int s = 0; s < P; ++s) {
-            th.acc_l[s] += th.x[s].y * w[s];   // swapped output: Re y = x.y, Im y = x.x
-            th.acc_r[s] += th.x[s].x * w[s];
+            th.acc_rl[s] = th.acc_rl[s] + scale(th.x[s], w[s]);   // swapped output: Ls = Re y = x.y, Rs = Im y = x.x
         }
 #pragma unroll
         for (int s = 0; s < HS; ++s) {
             const int n = e + s * LANES;
 #if defined(UPX_EXP) && UPX_EXP >= 5
-            if (emit && n <= last && th.acc_l[s] != th.acc_l[s]) {
+            if (emit && n <= last && th.acc_rl[s].y != th.acc_rl[s].y) {
 #else
             if (emit && n <= last) {
 #endif
-                out_l[n] = old_l[s] + th.acc_l[s];
-                out_r[n] = old_r[s] + th.acc_r[s];
+                out_l[n] = old_l[s] + th.acc_rl[s].y;
+                out_r[n] = old_r[s] + th.acc_rl[s].x;
             }
         }
 #pragma unroll
         for (int s = 0; s < P; ++s) {
-            th.acc_l[s] = s + HS < P ? th.acc_l[s + HS] : 0.f;
-            th.acc_r[s] = s + HS < P ? th.acc_r[s + HS] : 0.f;
+            th.acc_rl[s] = s + HS < P ? th.acc_rl[s + HS] : mk(0.f, 0.f);
         }
     };
     auto tail_c = [&](int tid, Thread& th, int it) {
@@ -733,12 +838,12 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             const bool dc = s == 0 && mir.first;   // k == 0
             const cf za = th.x[s];
             const cf zb = dc ? za : zpart[s];        // DC pairs with itself
-            const cf l0 = mk(za.x + zb.x, za.y - zb.y);   // Z[k] + conj Z[N-k]        (x gain/2 = L)
-            const cf r0 = mk(za.y + zb.y, zb.x - za.x);   // (Z[k] - conj Z[N-k]) / i  (x gain/2 = R)
+            const cf l0 = add_conj(za, zb);      // Z[k] + conj Z[N-k]        (x gain/2 = L)
+            const cf r0 = mi_sub_conj(za, zb);   // (Z[k] - conj Z[N-k]) / i  (x gain/2 = R)
             cf c = mk(0.f, 0.f), ls = c, rs = c;
             auto add_band = [&](float g2) {
                 if (g2 != 0.f) {   // whole waves lie outside the band: the branch skips them
-                    cf l = mk(g2 * l0.x, g2 * l0.y), r = mk(g2 * r0.x, g2 * r0.y), cq, lq, rq;
+                    cf l = scale(l0, g2), r = scale(r0, g2), cq, lq, rq;
                     mask_bin(l, r, cq, lq, rq);
                     c = c + cq; ls = ls + lq; rs = rs + rq;
                 }
@@ -754,14 +859,13 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
                 for (int q = 2; q < n_gain; ++q) add_band(gp[q * gstride]);
             }
             // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
-            const cf yk = mk(ls.x - rs.y, ls.y + rs.x);
-            const cf ym = mk(ls.x + rs.y, rs.x - ls.y);
-            th.x[s] = cswap(yk);
+            th.x[s] = swap_add_i(ls, rs);
+            const cf ym = swap_conj_add_i(ls, rs);
             if (s == 0) {
                 cf* dst = mir.first ? mir.nyq : mir.ymir + (H - 1) * SP;
-                *dst = cswap(mir.first ? nyq_y : ym);
+                *dst = mir.first ? cswap(nyq_y) : ym;
             } else {
-                mir.ymir[(H - 1 - s) * SP] = cswap(ym);
+                mir.ymir[(H - 1 - s) * SP] = ym;
             }
             // centre spectrum; the first lane's slot 0 packs the two real bins (DC, Nyquist)
             const cf cv = dc ? mk(c.x, nyq_c) : c;
@@ -769,15 +873,15 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
                 th.cs[s] = cv;
             } else {
                 const cf ca = th.cs[s], cb = cv;
-                // Yc[k] = Ca + i Cb ; Yc[N-k] = conj(Ca) + i conj(Cb)
-                cf ck = mk(ca.x - cb.y, ca.y + cb.x);
-                cf cm = mk(ca.x + cb.y, cb.x - ca.y);
+                // Yc[k] = Ca + i Cb ; Yc[N-k] = conj(Ca) + i conj(Cb), kept swapped
+                cf ck = swap_add_i(ca, cb);
+                cf cm = swap_conj_add_i(ca, cb);
                 if (dc) {
-                    ck = mk(ca.x, cb.x);   // Yc[0]
-                    cm = mk(ca.y, cb.y);   // Yc[N/2]
+                    ck = mk(cb.x, ca.x);   // swap(Yc[0])
+                    cm = mk(cb.y, ca.y);   // swap(Yc[N/2])
                 }
-                th.cs[s] = cswap(ck);
-                th.part[s] = cswap(cm);
+                th.cs[s] = ck;
+                th.part[s] = cm;
             }
         }
     };
@@ -797,8 +901,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         for (int s = 0; s < H; ++s) th.g0[s] = opaque(gain + s * LANES)[tid % LANES];
         th.gn[0] = gain[N / 2];
         th.gn[1] = a.n_gain > 1 ? gain[a.gain_stride + N / 2] : 0.f;
-        S::read_all(th, lds_all + (tid / SL) * BUF, tid % SL);
-        S::template pass_compute<LAST>(th, tw, tid % SL);
+        S::template read_compute<LAST>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
     };
     auto zsplit_write = [&](int tid, Thread& th) {
         cf* b = lds_all + (tid / SL) * BUF + padp<P>(tid % SL);
@@ -821,18 +924,19 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // wide only: first pass of a sub-FFT, and the end of an inverse sub-FFT (last pass, * W_N^(k1 n2), back
     // into the own buffer, from where final_pass reads columns after the barrier)
     auto sub_first = [&](int tid, Thread& th) {
-        S::read_all(th, lds_all + (tid / SL) * BUF, tid % SL);
-        S::template pass_compute<0>(th, tw, tid % SL);
+        S::template read_compute<0>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
     };
     auto sub_last_inv = [&](int tid, Thread& th) {
         if constexpr (WIDE) {
             const int g = tid / SL, sl = tid % SL;
             cf* b = lds_all + g * BUF + padp<P>(sl);
-            S::read_all(th, lds_all + g * BUF, sl);
-            S::template pass_compute<LAST>(th, tw, sl);
             const cf* bt = bigtw + wide_k1_of_sub(g) * C::BT_ROW + sl;   // row 0 is all ones
+            cf bw[P];
 #pragma unroll
-            for (int s = 0; s < P; ++s) b[s * SP] = cmul(th.x[s], lds_load(bt + s * SL));
+            for (int s = 0; s < P; ++s) bw[s] = lds_load(bt + s * SL);
+            S::template read_compute<LAST>(th, lds_all + g * BUF, tw, sl);
+#pragma unroll
+            for (int s = 0; s < P; ++s) b[s * SP] = cmul(th.x[s], bw[s]);
         }
     };
     // inverse transform from the staged input (own slots in registers, mirrors in LDS) up to the final pass
@@ -858,7 +962,10 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 
     ex.each([&](int tid, Thread& th) {
 #pragma unroll
-        for (int s = 0; s < P; ++s) th.acc_l[s] = th.acc_r[s] = th.acc_c[s] = 0.f;
+        for (int s = 0; s < P; ++s) {
+            th.acc_rl[s] = mk(0.f, 0.f);
+            th.acc_c[s] = 0.f;
+        }
         prefetch(tid, th, 0, 0);
     });
 
@@ -871,8 +978,10 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     for (; it <= n_iter; ++it) {
         ex.each2(
             [&](int tid, Thread& th) {
+                HeadRegs hr;
+                if (it < n_iter) head_fetch(tid, it, 0, hr);
                 if (it > 0) tail_c(tid, th, it - 1);
-                if (it < n_iter) head(tid, th, it, 0);
+                if (it < n_iter) head(tid, th, it, 0, hr);
             },
             [&](int tid, Thread& th) {
                 if (it < n_iter) head_write(tid, th);
@@ -881,8 +990,10 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         frame_body(0);
         ex.each2(
             [&](int tid, Thread& th) {
+                HeadRegs hr;
+                head_fetch(tid, it, 1, hr);
                 tail_lr(tid, th, it, 0);
-                head(tid, th, it, 1);
+                head(tid, th, it, 1, hr);
             },
             head_write);
         frame_body(1);
@@ -903,8 +1014,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
         for (int s = 0; s < P - HS; ++s) {
             seam[(0 * (P - HS) + s) * LANES] = th.acc_c[s];
-            seam[(1 * (P - HS) + s) * LANES] = th.acc_l[s];
-            seam[(2 * (P - HS) + s) * LANES] = th.acc_r[s];
+            seam[(1 * (P - HS) + s) * LANES] = th.acc_rl[s].y;
+            seam[(2 * (P - HS) + s) * LANES] = th.acc_rl[s].x;
         }
     });
     if constexpr (WIDE) ex.wg_barrier();
