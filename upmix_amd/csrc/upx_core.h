@@ -132,8 +132,10 @@ UPX_HD cf lds_load(const cf* p) { return *p; }
 // iterations across this point (it otherwise trades ~130 extra VGPRs for ILP).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define UPX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define UPX_ALL(c) (__builtin_amdgcn_ballot_w64(!(c)) == 0ull)   // true on every active lane of the wave
 #else
 #define UPX_SCHED_FENCE() ((void)0)
+#define UPX_ALL(c) (c)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 template <class T>
@@ -153,6 +155,25 @@ UPX_HD UPX_GLOBAL T* opaque(T* p) {
     asm volatile("" : "+s"(p));
 #endif
     return (UPX_GLOBAL T*)p;
+}
+
+// Element `voff + c` (in elements; c a compile-time constant) of a global array whose base is wave-uniform.
+// Written so that the backend emits `global_load/store v, v_off, s[base:base+1] offset:imm`: the base (plus
+// the part of c beyond the 12-bit immediate) stays in SGPRs, the only VGPR is the 32-bit byte offset, shared
+// by every slot of the array.  Byte offsets fit 32 bits because a launch covers < 2^29 samples.
+template <class T>
+UPX_HD UPX_GLOBAL T& gat(UPX_GLOBAL T* base, unsigned voff, int c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int cb = c * (int)sizeof(T);
+    UPX_GLOBAL char* b = (UPX_GLOBAL char*)base + (cb & ~4095);
+    return *(UPX_GLOBAL T*)(b + ((size_t)(voff * (unsigned)sizeof(T)) + (unsigned)(cb & 4095)));
+#else
+    return base[(size_t)voff + c];
+#endif
+}
+template <class T>
+UPX_HD const UPX_GLOBAL T& gat(const UPX_GLOBAL T* base, unsigned voff, int c) {
+    return gat(const_cast<UPX_GLOBAL T*>(base), voff, c);
 }
 
 // ---------------------------------------------------------------------------
@@ -458,11 +479,12 @@ struct Stream {
     // before the first multiply, in the order the butterfly consumes them (its first radix-4 takes inputs 0, 4, 8,
     // 12): left to itself the scheduler splits them into three batches and waits for each to come back in
     // full - three exposed LDS round trips per pass instead of one.
-    template <int PI>
+    // (EAGER = false where registers are scarce: the tail phases hold windows, old samples and the next frame.)
+    template <int PI, bool EAGER = true>
     static UPX_HD void read_compute(Thread& th, const cf* lds, const cf* tw, int lane) {
         constexpr int R = PS::r[PI];
         constexpr int NS = pass_ns(PS::r, PI);
-        if constexpr (R == P && P == 16) {
+        if constexpr (R == P && P == 16 && EAGER) {
             constexpr int OFF = tw_offset(PS::r, PI);
             const cf* b = lds + padp<P>(lane);
             const cf* row = tw + OFF + (lane & (NS - 1));
@@ -564,20 +586,24 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         exists = j >= a.j_lo && j < a.j_hi && j < m0 + F;
         return j;
     };
+    // Interior frames - all but the last few of a signal - take a branch-free path: one base address per array
+    // and immediate offsets per slot.  UPX_ALL makes the choice per wave, so the fast path has no per-slot
+    // clamps, compares or exec masks (they were a third of the instructions of these phases).
     auto prefetch = [&](int tid, Thread& th, int it, int half) {
         bool exists;
         const int j = frame_of(tid, it, half, exists);
         const int e = exists ? j * HOP + tid % LANES : 0;
         const UPX_GLOBAL cf* in = opaque(a.in);
         const int last = a.t_in - 1;
+        if (UPX_ALL(e + (P - 1) * LANES <= last)) {
 #pragma unroll
-        for (int s = P - HS; s < P; ++s) {
-            const int n = e + s * LANES;
-#if defined(UPX_EXP) && UPX_EXP >= 4
-            th.pre[s - (P - HS)] = mk(0.01f * (n & 7), 0.02f);
-#else
-            th.pre[s - (P - HS)] = in[n < last ? n : last];
-#endif
+            for (int s = P - HS; s < P; ++s) th.pre[s - (P - HS)] = gat(in, (unsigned)e, s * LANES);
+        } else {
+#pragma unroll
+            for (int s = P - HS; s < P; ++s) {
+                const int n = e + s * LANES;
+                th.pre[s - (P - HS)] = in[n < last ? n : last];
+            }
         }
     };
     // The samples a frame shares with its predecessor (L2 hits) and the analysis window.  Issued at the TOP of the
@@ -585,7 +611,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // them itself (it cannot tell the planes from the input), and a whole L2 round trip would be exposed.
     struct HeadRegs {
         cf v[P];      // first P-HS used
-        float w[P];
+        bool fast;    // the whole wave loads a frame that lies inside the signal
     };
     auto head_fetch = [&](int tid, int it, int half, HeadRegs& hr) {
         const int lane = tid % LANES;
@@ -593,41 +619,43 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const int j = frame_of(tid, it, half, exists);
         const int e = exists ? j * HOP + lane : 0;
         const UPX_GLOBAL cf* in = opaque(a.in);
-        const UPX_GLOBAL float* w_a = opaque(a.w_a);
         const int last = a.t_in - 1;   // host guarantees t_in >= 1
+        hr.fast = UPX_ALL(exists && e + (P - 1) * LANES <= last);
+        if (hr.fast) {
 #pragma unroll
-        for (int s = 0; s < P - HS; ++s) {
-            // always load an in-range sample; head() zeroes what lies past the signal or in a frame this
-            // stream does not own (zero-extension of center_extraction.py:437-455)
-            const int n = e + s * LANES;
-#if defined(UPX_EXP) && UPX_EXP >= 4
-            hr.v[s] = mk(0.01f * (n & 7), 0.02f);
-#else
-            hr.v[s] = in[n < last ? n : last];
-#endif
-        }
+            for (int s = 0; s < P - HS; ++s) hr.v[s] = gat(in, (unsigned)e, s * LANES);
+        } else {
 #pragma unroll
-        for (int s = 0; s < P; ++s) {
-#if defined(UPX_EXP) && UPX_EXP >= 3
-            hr.w[s] = 0.5f;
-#else
-            hr.w[s] = opaque(w_a + s * LANES)[lane];
-#endif
+            for (int s = 0; s < P - HS; ++s) {
+                // always load an in-range sample; head() zeroes what lies past the signal or in a frame this
+                // stream does not own (zero-extension of center_extraction.py:437-455)
+                const int n = e + s * LANES;
+                hr.v[s] = in[n < last ? n : last];
+            }
         }
         UPX_SCHED_FENCE();
     };
     auto head = [&](int tid, Thread& th, int it, int half, const HeadRegs& hr) {
         const int lane = tid % LANES;
-        bool exists;
-        const int j = frame_of(tid, it, half, exists);
-        const int e = exists ? j * HOP + lane : 0;
-        const int last = a.t_in - 1;
+        const UPX_GLOBAL float* w_a = opaque(a.w_a);
+        float wa[P];   // L1 / L2 hits
 #pragma unroll
-        for (int s = 0; s < P; ++s) {
-            const int n = e + s * LANES;
-            const cf v = s < P - HS ? hr.v[s] : th.pre[s < P - HS ? 0 : s - (P - HS)];
-            const float w = (exists && n <= last) ? hr.w[s] : 0.f;
-            th.x[s] = scale(v, w);
+        for (int s = 0; s < P; ++s) wa[s] = gat(w_a, (unsigned)lane, s * LANES);
+        if (hr.fast) {
+#pragma unroll
+            for (int s = 0; s < P; ++s) th.x[s] = scale(s < P - HS ? hr.v[s] : th.pre[s < P - HS ? 0 : s - (P - HS)], wa[s]);
+        } else {
+            bool exists;
+            const int j = frame_of(tid, it, half, exists);
+            const int e = exists ? j * HOP + lane : 0;
+            const int last = a.t_in - 1;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                const int n = e + s * LANES;
+                const cf v = s < P - HS ? hr.v[s] : th.pre[s < P - HS ? 0 : s - (P - HS)];
+                const float w = (exists && n <= last) ? wa[s] : 0.f;
+                th.x[s] = scale(v, w);
+            }
         }
         if constexpr (WIDE) {
             // radix-16 over n1 in registers, then W_N^(k1 n2) (n2 = tid)
@@ -650,7 +678,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             for (int r = 0; r < P; ++r) th.x[r] = lds_load(b + wide_sub_of_k1(r) * BUF);
             Dft<16>::run(th.x);
         } else {
-            S::template read_compute<LAST>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
+            S::template read_compute<LAST, false>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
         }
     };
     // first exchange of a forward transform
@@ -664,107 +692,105 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL);
         }
     };
-    // read-modify-write of one emitted hop: the old values are fetched BEFORE the final pass
-    // so that their HBM latency overlaps the butterflies
+    // One emitted hop of a plane: the old values (band sum in list order) are fetched BEFORE the final pass so
+    // that their latency overlaps the butterflies; so is the synthesis window.
+    struct Hop {
+        int e;        // first sample of this lane's part of the hop (0 if nothing is emitted)
+        bool emit;    // this stream emits the hop
+        bool fast;    // the whole wave emits a hop that lies inside the planes
+    };
+    auto hop_of = [&](int tid, int j) {
+        const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
+        Hop h;
+        h.emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
+        h.e = h.emit ? j * HOP + tid % LANES : 0;
+        h.fast = UPX_ALL(h.emit && h.e + (HS - 1) * LANES <= a.t_out - 1);
+        return h;
+    };
+    auto load_old = [&](UPX_GLOBAL float* plane, const Hop& h, float* old) {
+        if (!a.accumulate) {
+#pragma unroll
+            for (int s = 0; s < HS; ++s) old[s] = 0.f;
+        } else if (h.fast) {
+#pragma unroll
+            for (int s = 0; s < HS; ++s) old[s] = gat(plane, (unsigned)h.e, s * LANES);
+        } else {
+            const int last = a.t_out - 1;
+#pragma unroll
+            for (int s = 0; s < HS; ++s) {
+                const int n = h.e + s * LANES;
+                old[s] = plane[n < last ? n : last];
+            }
+        }
+    };
     auto tail_lr = [&](int tid, Thread& th, int it, int half) {
         const int lane = tid % LANES;
         const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
-        const int j = m0 + 2 * it + half;
-        const bool emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
-        const int e = emit ? j * HOP + lane : 0;
+        const Hop h = hop_of(tid, m0 + 2 * it + half);
         UPX_GLOBAL float* out_l = opaque(a.out_l);
         UPX_GLOBAL float* out_r = opaque(a.out_r);
-        const int last = a.t_out - 1;
         float old_l[HS], old_r[HS];
-#pragma unroll
-        for (int s = 0; s < HS; ++s) {
-            const int n = e + s * LANES;
-            const int nc = n < last ? n : last;
-#if defined(UPX_EXP) && UPX_EXP >= 5
-            old_l[s] = 0.f; old_r[s] = 0.f; (void)nc;
-#else
-            old_l[s] = a.accumulate ? out_l[nc] : 0.f;
-            old_r[s] = a.accumulate ? out_r[nc] : 0.f;
-#endif
-        }
-        // synthesis window: fetched before the final pass so the L2 latency hides behind the butterflies
+        load_old(out_l, h, old_l);
+        load_old(out_r, h, old_r);
         const UPX_GLOBAL float* w_s = opaque(a.w_s);
         float w[P];
 #pragma unroll
-#if defined(UPX_EXP) && UPX_EXP >= 3
-        for (int s = 0; s < P; ++s) w[s] = 0.001f;
-#else
-        for (int s = 0; s < P; ++s) w[s] = opaque(w_s + s * LANES)[lane];
-#endif
+        for (int s = 0; s < P; ++s) w[s] = gat(w_s, (unsigned)lane, s * LANES);
         final_pass(tid, th);
 #pragma unroll
-        for (int s = 0; s < P; ++s) {
+        for (int s = 0; s < P; ++s)
             th.acc_rl[s] = th.acc_rl[s] + scale(th.x[s], w[s]);   // swapped output: Ls = Re y = x.y, Rs = Im y = x.x
-        }
+        if (h.fast) {
 #pragma unroll
-        for (int s = 0; s < HS; ++s) {
-            const int n = e + s * LANES;
-#if defined(UPX_EXP) && UPX_EXP >= 5
-            if (emit && n <= last && th.acc_rl[s].y != th.acc_rl[s].y) {
-#else
-            if (emit && n <= last) {
-#endif
-                out_l[n] = old_l[s] + th.acc_rl[s].y;
-                out_r[n] = old_r[s] + th.acc_rl[s].x;
+            for (int s = 0; s < HS; ++s) {
+                gat(out_l, (unsigned)h.e, s * LANES) = old_l[s] + th.acc_rl[s].y;
+                gat(out_r, (unsigned)h.e, s * LANES) = old_r[s] + th.acc_rl[s].x;
+            }
+        } else {
+            const int last = a.t_out - 1;
+#pragma unroll
+            for (int s = 0; s < HS; ++s) {
+                const int n = h.e + s * LANES;
+                if (h.emit && n <= last) {
+                    out_l[n] = old_l[s] + th.acc_rl[s].y;
+                    out_r[n] = old_r[s] + th.acc_rl[s].x;
+                }
             }
         }
 #pragma unroll
-        for (int s = 0; s < P; ++s) {
-            th.acc_rl[s] = s + HS < P ? th.acc_rl[s + HS] : mk(0.f, 0.f);
-        }
+        for (int s = 0; s < P; ++s) th.acc_rl[s] = s + HS < P ? th.acc_rl[s + HS] : mk(0.f, 0.f);
     };
     auto tail_c = [&](int tid, Thread& th, int it) {
         const int lane = tid % LANES;
         const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
         UPX_GLOBAL float* out_c = opaque(a.out_c);
-        const int last = a.t_out - 1;
-        const int ja = m0 + 2 * it;
+        Hop h[2];
         float old_c[2][HS];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int j = ja + half;
-            const bool emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
-            const int e = emit ? j * HOP + lane : 0;
-#pragma unroll
-            for (int s = 0; s < HS; ++s) {
-                const int n = e + s * LANES;
-#if defined(UPX_EXP) && UPX_EXP >= 5
-                old_c[half][s] = 0.f;
-#else
-                old_c[half][s] = a.accumulate ? out_c[n < last ? n : last] : 0.f;
-#endif
-            }
+            h[half] = hop_of(tid, m0 + 2 * it + half);
+            load_old(out_c, h[half], old_c[half]);
         }
         const UPX_GLOBAL float* w_s = opaque(a.w_s);
         float w[P];
 #pragma unroll
-#if defined(UPX_EXP) && UPX_EXP >= 3
-        for (int s = 0; s < P; ++s) w[s] = 0.001f;
-#else
-        for (int s = 0; s < P; ++s) w[s] = opaque(w_s + s * LANES)[lane];
-#endif
+        for (int s = 0; s < P; ++s) w[s] = gat(w_s, (unsigned)lane, s * LANES);
         final_pass(tid, th);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int j = ja + half;
 #pragma unroll
             for (int s = 0; s < P; ++s)   // swapped output: c_a = Re y = x.y ; c_b = Im y = x.x
                 th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w[s];
-            const bool emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
-            const int e = emit ? j * HOP + lane : 0;
+            if (h[half].fast) {
 #pragma unroll
-            for (int s = 0; s < HS; ++s) {
-                const int n = e + s * LANES;
-#if defined(UPX_EXP) && UPX_EXP >= 5
-                if (emit && n <= last && th.acc_c[s] != th.acc_c[s]) out_c[n] = old_c[half][s] + th.acc_c[s];
-#else
-                if (emit && n <= last) out_c[n] = old_c[half][s] + th.acc_c[s];
-#endif
+                for (int s = 0; s < HS; ++s) gat(out_c, (unsigned)h[half].e, s * LANES) = old_c[half][s] + th.acc_c[s];
+            } else {
+                const int last = a.t_out - 1;
+#pragma unroll
+                for (int s = 0; s < HS; ++s) {
+                    const int n = h[half].e + s * LANES;
+                    if (h[half].emit && n <= last) out_c[n] = old_c[half][s] + th.acc_c[s];
+                }
             }
 #pragma unroll
             for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
@@ -812,7 +838,11 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const int n_gain = a.n_gain, gstride = a.gain_stride;
         float g1[H];
 #pragma unroll
-        for (int s = 0; s < H; ++s) g1[s] = n_gain > 1 ? opaque(gain + s * LANES)[gstride + lane] : 0.f;
+        for (int s = 0; s < H; ++s) g1[s] = 0.f;
+        if (n_gain > 1) {
+#pragma unroll
+            for (int s = 0; s < H; ++s) g1[s] = gat(gain + gstride, (unsigned)lane, s * LANES);
+        }
         if (mir.first) {
             // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
             const cf z = th.x[H];
@@ -855,8 +885,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             add_band(th.g0[s]);
             if (n_gain > 1) {
                 add_band(g1[s]);
-                const UPX_GLOBAL float* gp = opaque(gain + s * LANES) + lane;
-                for (int q = 2; q < n_gain; ++q) add_band(gp[q * gstride]);
+                for (int q = 2; q < n_gain; ++q) add_band(gat(gain + q * gstride, (unsigned)lane, s * LANES));
             }
             // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
             th.x[s] = swap_add_i(ls, rs);
@@ -898,7 +927,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     auto zsplit_compute = [&](int tid, Thread& th) {
         const UPX_GLOBAL float* gain = opaque(a.gain);
 #pragma unroll
-        for (int s = 0; s < H; ++s) th.g0[s] = opaque(gain + s * LANES)[tid % LANES];
+        for (int s = 0; s < H; ++s) th.g0[s] = gat(gain, (unsigned)(tid % LANES), s * LANES);
         th.gn[0] = gain[N / 2];
         th.gn[1] = a.n_gain > 1 ? gain[a.gain_stride + N / 2] : 0.f;
         S::template read_compute<LAST>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
