@@ -217,7 +217,7 @@ def main():
         dom_ms = float(band_ms[dom])
         algo_bytes = ALGO_BYTES_PER_SAMPLE_BAND * own * groups[dom]
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-        tag = f"upx_band_kernel<upx::Cfg<{int(np.log2(sizes[dom]))}, 4, 16>, 2>"   # kernel symbol as rocprofv3 prints it
+        tag = plan.band_kernel_name(dom)   # kernel symbol as rocprofv3 prints it
         out = {
             "metric": "stereo Msamples/sec upmixed (6-band, STFT<=8192)",
             "value": round(value, 2),

@@ -111,6 +111,10 @@ int upx_plan_band_times_ms(upx_plan* plan, float* ms, int n_bands);
 /* Kernel symbol name / launch geometry of a band (for profiles and DESIGN.md). */
 int upx_plan_band_info(upx_plan* plan, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,
                        int32_t* blocks_per_stream);
+/* Name of the kernel that carries `band`, as rocprofv3 prints it (NUL-terminated, truncated to n bytes):
+   "upx_band_kernel<upx::WideCfg<13, 4>, 2>", "upx_band_kernel<upx::Cfg<10, 4, 16>, 2>", or
+   "unfused<N>" for the multi-kernel path (upx_big_* kernels). */
+int upx_plan_band_kernel_name(upx_plan* plan, int band, char* name, size_t n);
 
 /*
  * Adjacent bands with the same STFT size, hop and windows are merged into ONE kernel launch (their

@@ -448,3 +448,30 @@ def test_pathological_signals(ux, orc):
         for g, r in zip(got, ref):
             assert np.all(np.isfinite(g)), name
             assert rms((g.astype(np.float64) - r) / scale) <= TOL, name
+
+
+def test_kernel_flavours_agree(ux, orc, monkeypatch):
+    """Wide streams (default for STFT 4096 / 8192), the plain Stockham schedule (UPX_KERNEL_VARIANT=2) and the
+    8-points-per-lane kernels (=1) are different routings of the same arithmetic: each within tolerance of the
+    oracle, and within float32 rounding of one another."""
+    x = orc.synthetic_stereo(150000, 21)
+    edges, tf = [0, 120, 480, 4000], 32
+    ref_bands = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, 48000, max_block_size=8192, threshold_factor=tf)
+    assert sorted({b.block_size for b in ref_bands}) == [512, 4096, 8192]
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ref_bands)
+    outs, names = {}, {}
+    for variant in ("0", "2", "1"):
+        monkeypatch.setenv("UPX_KERNEL_VARIANT", variant)
+        bands = gpu_chain(ux, edges, 48000, 8192, tf)
+        plan = ux.DevicePlan(bands)
+        names[variant] = [plan.band_kernel_name(i) for i in range(len(bands))]
+        outs[variant] = plan.process(x)
+        plan.close()
+        for got, r in zip(outs[variant], ref):
+            close(got, r)
+    assert any("WideCfg<13, 4>" in n for n in names["0"]) and any("WideCfg<12, 4>" in n for n in names["0"])
+    assert not any("Wide" in n for n in names["2"]) and any("Cfg<13, 4, 16>" in n for n in names["2"])
+    assert any("Cfg<13, 4, 8>" in n for n in names["1"])
+    for v in ("2", "1"):
+        for a, b in zip(outs["0"], outs[v]):
+            assert rms(a.astype(np.float64) - b) < 1e-7

@@ -325,14 +325,14 @@ const KernelEntry* find_kernel(int log2n, int k, int variant) {
     static const std::map<std::tuple<int, int, int>, KernelEntry> table = [] {
         std::map<std::tuple<int, int, int>, KernelEntry> t;
 #define UPX_REG(L, K, PP, W, V) \
-    t[std::make_tuple(L, K, V)] = Entry<upx::Cfg<L, K, PP>, W>::get("upx_band_kernel<Cfg<" #L "," #K "," #PP ">," #W ">");
+    t[std::make_tuple(L, K, V)] = Entry<upx::Cfg<L, K, PP>, W>::get("upx_band_kernel<upx::Cfg<" #L ", " #K ", " #PP ">, " #W ">");
 #define UPX_REG_SIZES(K, PP, W, V) \
     UPX_REG(8, K, PP, W, V) UPX_REG(9, K, PP, W, V) UPX_REG(10, K, PP, W, V) UPX_REG(11, K, PP, W, V) \
     UPX_REG(12, K, PP, W, V) UPX_REG(13, K, PP, W, V)
 #define UPX_REG_SMALL(K, PP, W, V) \
     UPX_REG(8, K, PP, W, V) UPX_REG(9, K, PP, W, V) UPX_REG(10, K, PP, W, V) UPX_REG(11, K, PP, W, V)
 #define UPX_REG_WIDE(L, K) \
-    t[std::make_tuple(L, K, 0)] = Entry<upx::WideCfg<L, K>, 2>::get("upx_band_kernel<WideCfg<" #L "," #K ">,2>");
+    t[std::make_tuple(L, K, 0)] = Entry<upx::WideCfg<L, K>, 2>::get("upx_band_kernel<upx::WideCfg<" #L ", " #K ">, 2>");
         UPX_REG_SMALL(2, 16, 2, 0) UPX_REG_SMALL(4, 16, 2, 0) UPX_REG_SMALL(8, 16, 2, 0)
         UPX_REG_WIDE(12, 2) UPX_REG_WIDE(12, 4) UPX_REG_WIDE(12, 8) UPX_REG_WIDE(13, 2) UPX_REG_WIDE(13, 4) UPX_REG_WIDE(13, 8)
         UPX_REG_SIZES(2, 8, 4, 1) UPX_REG_SIZES(4, 8, 4, 1) UPX_REG_SIZES(8, 8, 4, 1)
@@ -828,6 +828,15 @@ int upx_plan_band_info(upx_plan* p, int band, int32_t* workgroups, int32_t* thre
     if (threads) *threads = s.kern ? s.kern->wg : s.big->row_wg;
     if (lds_bytes) *lds_bytes = s.kern ? s.kern->lds_bytes : s.big->row_lds;
     if (blocks_per_stream) *blocks_per_stream = s.last_f;
+    return UPX_OK;
+}
+
+int upx_plan_band_kernel_name(upx_plan* p, int band, char* name, size_t n) {
+    if (!p || !name || n == 0 || band < 0 || band >= (int)p->bands.size())
+        return fail(UPX_ERR_INVALID, "upx_plan_band_kernel_name: bad argument");
+    const BandState& s = p->bands[p->bands[band].group_leader];
+    if (s.kern) std::snprintf(name, n, "%s", s.kern->name);
+    else std::snprintf(name, n, "unfused<%d>", s.n);
     return UPX_OK;
 }
 

@@ -111,6 +111,12 @@ class DevicePlan:
         return {"workgroups": v[0].value, "threads": v[1].value, "lds_bytes": v[2].value,
                 "blocks_per_stream": v[3].value}
 
+    def band_kernel_name(self, band: int) -> str:
+        """Kernel symbol (as rocprofv3 prints it) of the launch that carries `band`."""
+        buf = C.create_string_buffer(128)
+        _lib.check(self._lib.upx_plan_band_kernel_name(self.handle, int(band), buf, len(buf)))
+        return buf.value.decode()
+
     def band_group(self, band: int):
         """(leader, size) of the merged launch that carries `band`."""
         a, b = C.c_int32(), C.c_int32()
