@@ -421,6 +421,7 @@ struct ThreadT {
     cf part[P / 2];   // Yc[N-k] of the pair
     cf pre[P];        // (first P/K used) raw samples of the NEXT frame's new hop, fetched one frame ahead
     float g0[P / 2];  // first gain slot of the own bins, fetched one phase ahead of the mask
+    float g1[P / 2];  // second slot (merged bands)
     float gn[2];      // first two gain slots of the Nyquist bin
 };
 
@@ -621,12 +622,13 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const UPX_GLOBAL cf* in = opaque(a.in);
         const int last = a.t_in - 1;   // host guarantees t_in >= 1
         hr.fast = UPX_ALL(exists && e + (P - 1) * LANES <= last);
+        constexpr int NFETCH = P - HS;
         if (hr.fast) {
 #pragma unroll
-            for (int s = 0; s < P - HS; ++s) hr.v[s] = gat(in, (unsigned)e, s * LANES);
+            for (int s = 0; s < NFETCH; ++s) hr.v[s] = gat(in, (unsigned)e, s * LANES);
         } else {
 #pragma unroll
-            for (int s = 0; s < P - HS; ++s) {
+            for (int s = 0; s < NFETCH; ++s) {
                 // always load an in-range sample; head() zeroes what lies past the signal or in a frame this
                 // stream does not own (zero-extension of center_extraction.py:437-455)
                 const int n = e + s * LANES;
@@ -836,13 +838,6 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         cf nyq_y = mk(0.f, 0.f);
         float nyq_c = 0.f;
         const int n_gain = a.n_gain, gstride = a.gain_stride;
-        float g1[H];
-#pragma unroll
-        for (int s = 0; s < H; ++s) g1[s] = 0.f;
-        if (n_gain > 1) {
-#pragma unroll
-            for (int s = 0; s < H; ++s) g1[s] = gat(gain + gstride, (unsigned)lane, s * LANES);
-        }
         if (mir.first) {
             // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
             const cf z = th.x[H];
@@ -884,7 +879,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             // plain: bin lane + s LANES.  wide: the table is stored in the kernel's bin order (gain_bin)
             add_band(th.g0[s]);
             if (n_gain > 1) {
-                add_band(g1[s]);
+                add_band(th.g1[s]);
                 for (int q = 2; q < n_gain; ++q) add_band(gat(gain + q * gstride, (unsigned)lane, s * LANES));
             }
             // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
@@ -930,6 +925,13 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         for (int s = 0; s < H; ++s) th.g0[s] = gat(gain, (unsigned)(tid % LANES), s * LANES);
         th.gn[0] = gain[N / 2];
         th.gn[1] = a.n_gain > 1 ? gain[a.gain_stride + N / 2] : 0.f;
+        // (always written: a value kept from the previous frame would be live through the whole loop)
+#pragma unroll
+        for (int s = 0; s < H; ++s) th.g1[s] = 0.f;
+        if (a.n_gain > 1) {
+#pragma unroll
+            for (int s = 0; s < H; ++s) th.g1[s] = gat(gain + a.gain_stride, (unsigned)(tid % LANES), s * LANES);
+        }
         S::template read_compute<LAST>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
     };
     auto zsplit_write = [&](int tid, Thread& th) {
