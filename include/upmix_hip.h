@@ -78,11 +78,20 @@ int upx_plan_set_blocks_per_stream(upx_plan* plan, int band, int blocks);
  *   stereo  interleaved float32 [T][2] (L, R)
  *   out_c/out_l/out_r  float32 [T] each: centre, left-side, right-side
  * Replaces extract_center_left_right_multi_band_in_memory (:477-513); same
- * (center, left, right) order.  n_samples < 2^29 per call (byte offsets are 32-bit inside the
- * kernels); longer signals are time-sharded by the caller with upx_process_device +
- * upx_seam_add_local (upmix_amd/sharding.py does this transparently).
+ * (center, left, right) order.  Any length: a launch covers < 2^29 samples (byte offsets are 32-bit inside
+ * the kernels), longer signals - and by default every long signal - go through upx_process_chunked().
  */
 int upx_process(upx_plan* plan, const float* stereo, int64_t n_samples, float* out_c, float* out_l, float* out_r);
+/*
+ * The same, streamed: the signal is cut into chunks of about `chunk` samples (rounded to the bands' common frame
+ * grid); the upload of chunk i+1, the kernels of chunk i and the download of chunk i-1 overlap, and each chunk's
+ * overlap-add tail is added onto the next chunk on the device.  Device memory is O(chunk), so signals larger
+ * than HBM or longer than 2^29 samples work.  upx_process() calls this for long signals (from 2 chunks of 2^22
+ * samples; UPX_STREAM_CHUNK overrides the chunk length, 0 disables).  Differs from the one-shot result only by the
+ * float32 association of the overlap-add at the chunk seams (same as a multi-GPU run).
+ */
+int upx_process_chunked(upx_plan* plan, const float* stereo, int64_t n_samples, float* out_c, float* out_l,
+                        float* out_r, int64_t chunk);
 
 /* ---- device-resident interface (benchmarks, sharding, pipelines) -------- */
 int upx_dev_alloc(upx_plan* plan, void** ptr, size_t bytes);

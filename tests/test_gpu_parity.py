@@ -475,3 +475,35 @@ def test_kernel_flavours_agree(ux, orc, monkeypatch):
     for v in ("2", "1"):
         for a, b in zip(outs["0"], outs[v]):
             assert rms(a.astype(np.float64) - b) < 1e-7
+
+
+def test_streamed_host_call(ux, orc, monkeypatch):
+    """upx_process_chunked: upload / kernels / download of consecutive chunks overlap, each chunk's overlap-add
+    tail is added onto the next on the device.  Any chunk length gives the one-shot result up to the float32
+    association at the chunk seams; upx_process streams by itself once a signal spans two chunks."""
+    x = orc.synthetic_stereo(700001, 31)
+    bands = gpu_chain(ux, [0, 300, 3000], 48000, 4096, 64)
+    plan = ux.DevicePlan(bands)
+    monkeypatch.setenv("UPX_STREAM_CHUNK", "0")
+    base = plan.process(x)
+    ref_bands = orc.plan_bands([0, 300, 3000], 0.75, orc.win_blackman_harris, 48000, max_block_size=4096, threshold_factor=64)
+    ref = orc.extract_multi_band(x[:150000, 0].astype(np.float64), x[:150000, 1].astype(np.float64), ref_bands)
+    for chunk in (1, 5000, 65536, 200000, 699999, 1 << 22):
+        got = plan.process_chunked(x, chunk)
+        for u, v, r in zip(base, got, ref):
+            assert np.all(np.isfinite(v))
+            assert float(np.max(np.abs(u - v))) < 1e-6, chunk
+            close(v[:140000], r[:140000])
+    monkeypatch.setenv("UPX_STREAM_CHUNK", "100000")   # upx_process streams from two chunks on
+    for u, v in zip(base, plan.process(x)):
+        assert float(np.max(np.abs(u - v))) < 1e-6
+    # ragged tails: last chunk shorter than the spill, signal shorter than a chunk
+    for total in (3, 4097, 12288 + 5, 24576 + 4095):
+        xs = x[:total]
+        one = plan.process(xs) if total < 200000 else None
+        monkeypatch.setenv("UPX_STREAM_CHUNK", "0")
+        one = plan.process(xs)
+        got = plan.process_chunked(xs, 4096)
+        for u, v in zip(one, got):
+            assert u.shape == v.shape == (total,) and float(np.max(np.abs(u - v))) < 1e-6, total
+    plan.close()

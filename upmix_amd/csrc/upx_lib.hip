@@ -9,7 +9,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <string>
 #include <tuple>
@@ -392,6 +395,15 @@ struct upx_plan {
     size_t seam_floats = 0;
     upx::cf* d_scratch = nullptr;   // z | y | yc of the big path (shared by all big bands)
     size_t scratch_cf = 0;
+    // streamed host calls (upx_process on long signals): copy streams, events and two rotating buffer sets
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr};
+    float* d_pipe_in[2] = {nullptr, nullptr};
+    float* d_pipe_out[2] = {nullptr, nullptr};
+    size_t pipe_in_floats = 0, pipe_out_floats = 0;
+    // device buffers of upx_wav_pipeline, kept between calls (grow only): pcm in, stereo, planes, 3 outputs
+    void* d_wav[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t wav_cap[6] = {0, 0, 0, 0, 0, 0};
 };
 
 struct upx_comm {
@@ -616,6 +628,15 @@ void upx_plan_destroy(upx_plan* p) {
     if (p->d_scalar) (void)hipFree(p->d_scalar);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->d_seam) (void)hipFree(p->d_seam);
+    for (int i = 0; i < 2; ++i) {
+        if (p->d_pipe_in[i]) (void)hipFree(p->d_pipe_in[i]);
+        if (p->d_pipe_out[i]) (void)hipFree(p->d_pipe_out[i]);
+        if (p->ev_h2d[i]) (void)hipEventDestroy(p->ev_h2d[i]);
+        if (p->ev_comp[i]) (void)hipEventDestroy(p->ev_comp[i]);
+    }
+    for (auto* q : p->d_wav) if (q) (void)hipFree(q);
+    if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
+    if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     delete p;
 }
@@ -768,10 +789,177 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
     return UPX_OK;
 }
 
+// Time-shard geometry shared by all bands: cuts sit on multiples of 2 hop_max (so local frame
+// parity equals global frame parity in every band), a shard reads `spill` samples past its end and its output
+// spills the same number of samples into the next shard.  Returns false when the hops do not share a grid.
+static bool shard_geometry(const upx_plan* p, int64_t* grid, int64_t* spill) {
+    int64_t hop_max = 0, sp = 0;
+    for (const auto& s : p->bands) {
+        if (s.hop > hop_max) hop_max = s.hop;
+        if (s.n - s.hop > sp) sp = s.n - s.hop;
+    }
+    for (const auto& s : p->bands)
+        if (hop_max % s.hop) return false;
+    *grid = 2 * hop_max;
+    *spill = sp;
+    return true;
+}
+
+int upx_process_chunked(upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r,
+                        int64_t chunk) {
+    if (!p || n < 0 || chunk < 1) return fail(UPX_ERR_INVALID, "upx_process_chunked: bad argument");
+    if (n == 0) return UPX_OK;
+    if (!stereo || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process_chunked: NULL buffer");
+    int64_t grid = 0, spill = 0;
+    if (!shard_geometry(p, &grid, &spill))
+        return fail(UPX_ERR_UNSUPPORTED, "the bands' hops do not share a shard grid: the signal cannot be cut into chunks");
+    // owned samples per chunk: a multiple of the grid, at least the spill (a seam then ends inside the next chunk)
+    int64_t own = (chunk + grid - 1) / grid * grid;
+    if (own < spill) own = (spill + grid - 1) / grid * grid;
+    if (own + spill >= (1LL << 29)) return fail(UPX_ERR_INVALID, "chunk too long (2^29 samples per launch)");
+    const int64_t n_chunks = (n + own - 1) / own;
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->s_h2d) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_h2d[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->ev_comp[i], hipEventDisableTiming));
+        }
+    }
+    const size_t in_floats = (size_t)(own + spill) * 2, out_floats = (size_t)(own + spill) * 3;
+    if (in_floats > p->pipe_in_floats || out_floats > p->pipe_out_floats) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (int i = 0; i < 2; ++i) {
+            if (p->d_pipe_in[i]) HIP_TRY(hipFree(p->d_pipe_in[i]));
+            if (p->d_pipe_out[i]) HIP_TRY(hipFree(p->d_pipe_out[i]));
+            p->d_pipe_in[i] = p->d_pipe_out[i] = nullptr;
+        }
+        p->pipe_in_floats = p->pipe_out_floats = 0;
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipMalloc(&p->d_pipe_in[i], in_floats * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc(&p->d_pipe_out[i], out_floats * sizeof(float));
+            if (e != hipSuccess) return fail(UPX_ERR_NOMEM, "hipMalloc for a %lld-sample chunk: %s", (long long)own, hipGetErrorString(e));
+        }
+        p->pipe_in_floats = in_floats;
+        p->pipe_out_floats = out_floats;
+    }
+    const size_t plane = (size_t)(own + spill);
+
+    // The host thread uploads chunk i+1 while the GPU transforms chunk i; a second thread waits for each
+    // chunk's kernels and downloads its owned range (a download into pageable memory blocks its caller, so it
+    // cannot share the uploading thread).  Buffer set i % 2 is reused by chunk i+2 once that download is done.
+    struct Shared {
+        std::mutex m;
+        std::condition_variable cv;
+        int64_t submitted = 0, downloaded = 0;
+        bool abort = false;
+        int rc = UPX_OK;
+        std::string err;
+    } sh;
+    std::thread downloader([&] {
+        (void)hipSetDevice(p->device);
+        for (int64_t i = 0; i < n_chunks; ++i) {
+            {
+                std::unique_lock<std::mutex> lk(sh.m);
+                sh.cv.wait(lk, [&] { return sh.submitted > i || sh.abort; });
+                if (sh.submitted <= i) return;
+            }
+            const int b = (int)(i & 1);
+            const int64_t start = i * own;
+            const int64_t cnt = (n - start < own ? n - start : own);
+            hipError_t e = hipEventSynchronize(p->ev_comp[b]);
+            float* outs[3] = {out_c, out_l, out_r};
+            for (int k = 0; k < 3 && e == hipSuccess; ++k)
+                e = hipMemcpyAsync(outs[k] + start, p->d_pipe_out[b] + k * plane, (size_t)cnt * sizeof(float),
+                                   hipMemcpyDeviceToHost, p->s_d2h);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->s_d2h);
+            std::lock_guard<std::mutex> lk(sh.m);
+            if (e != hipSuccess && sh.rc == UPX_OK) {
+                sh.rc = UPX_ERR_HIP;
+                sh.err = std::string("download of a chunk failed: ") + hipGetErrorString(e);
+            }
+            sh.downloaded = i + 1;
+            sh.cv.notify_all();
+        }
+    });
+    int rc = UPX_OK;
+    std::string err;
+    for (int64_t i = 0; i < n_chunks && rc == UPX_OK; ++i) {
+        const int b = (int)(i & 1);
+        const int64_t start = i * own;
+        const bool last = i == n_chunks - 1;
+        const int64_t cnt = last ? n - start : own;
+        const int64_t t_in = n - start < cnt + spill ? n - start : cnt + spill;
+        const int64_t t_out = last ? cnt : cnt + spill;
+        if (i >= 2) {   // buffer set b: chunk i-2 must be downloaded (its kernels are then done as well)
+            std::unique_lock<std::mutex> lk(sh.m);
+            sh.cv.wait(lk, [&] { return sh.downloaded >= i - 1 || sh.rc != UPX_OK; });
+            if (sh.rc != UPX_OK) break;
+        }
+        hipError_t e = hipMemcpyAsync(p->d_pipe_in[b], stereo + 2 * start, (size_t)t_in * 2 * sizeof(float),
+                                      hipMemcpyHostToDevice, p->s_h2d);
+        if (e == hipSuccess) e = hipEventRecord(p->ev_h2d[b], p->s_h2d);
+        if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, p->ev_h2d[b], 0);
+        if (e != hipSuccess) {
+            rc = UPX_ERR_HIP;
+            err = std::string("upload of a chunk failed: ") + hipGetErrorString(e);
+            break;
+        }
+        float* o = p->d_pipe_out[b];
+        rc = upx_process_device(p, p->d_pipe_in[b], t_in, cnt, o, o + plane, o + 2 * plane, t_out);
+        if (rc == UPX_OK && i > 0) {
+            const float* q = p->d_pipe_out[b ^ 1];
+            rc = upx_seam_add_local(p, q, q + plane, q + 2 * plane, own, o, o + plane, o + 2 * plane,
+                                    spill < t_out ? spill : t_out);
+        }
+        if (rc != UPX_OK) {
+            err = g_err;
+            break;
+        }
+        e = hipEventRecord(p->ev_comp[b], p->stream);
+        if (e != hipSuccess) {
+            rc = UPX_ERR_HIP;
+            err = std::string("hipEventRecord: ") + hipGetErrorString(e);
+            break;
+        }
+        std::lock_guard<std::mutex> lk(sh.m);
+        sh.submitted = i + 1;
+        sh.cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> lk(sh.m);
+        if (rc != UPX_OK) sh.abort = true;
+        sh.cv.notify_all();
+    }
+    downloader.join();
+    (void)hipStreamSynchronize(p->stream);
+    if (rc == UPX_OK && sh.rc != UPX_OK) {
+        rc = sh.rc;
+        err = sh.err;
+    }
+    if (rc != UPX_OK) return fail((upx_status)rc, "%s", err.c_str());
+    return UPX_OK;
+}
+
 int upx_process(upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r) {
     if (!p || n < 0) return fail(UPX_ERR_INVALID, "upx_process: bad argument");
     if (n == 0) return UPX_OK;
     if (!stereo || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process: NULL buffer");
+    {
+        // long signals stream through the device in chunks (uploads, kernels and downloads overlap; no limit
+        // on the length).  UPX_STREAM_CHUNK = samples per chunk, 0 = never stream.
+        const char* env = std::getenv("UPX_STREAM_CHUNK");
+        const int64_t chunk = env ? std::atoll(env) : (1LL << 22);
+        int64_t grid = 0, spill = 0;
+        if (chunk > 0 && n >= 2 * chunk && shard_geometry(p, &grid, &spill) && chunk >= 4 * spill)
+            return upx_process_chunked(p, stereo, n, out_c, out_l, out_r, chunk);
+        if (n >= (1LL << 29)) {
+            if (!shard_geometry(p, &grid, &spill))
+                return fail(UPX_ERR_INVALID, "signals of 2^29 samples or more need hops that share a shard grid");
+            return upx_process_chunked(p, stereo, n, out_c, out_l, out_r, 1LL << 26);
+        }
+    }
     HIP_TRY(hipSetDevice(p->device));
     float *d_in = nullptr, *d_out = nullptr;
     hipError_t e = hipMalloc(&d_in, (size_t)n * 2 * sizeof(float));
@@ -893,23 +1081,33 @@ int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channel
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int rc = UPX_OK;
     auto cleanup = [&]() {
-        if (d_pcm) (void)hipFree(d_pcm);
-        if (d_st) (void)hipFree(d_st);
-        if (d_pl) (void)hipFree(d_pl);
-        for (auto* q : d_o) if (q) (void)hipFree(q);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     };
 #define PIPE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(UPX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    PIPE_TRY(hipMalloc(&d_pcm, in_bytes));
-    PIPE_TRY(hipMalloc(&d_st, (size_t)n * 2 * sizeof(float)));
-    PIPE_TRY(hipMalloc(&d_pl, (size_t)n * 3 * sizeof(float)));
-    for (int i = 0; i < n_out; ++i) PIPE_TRY(hipMalloc(&d_o[i], out_bytes));
+    // device buffers live in the plan and only grow: allocating and freeing ~0.8 GB per call costs more than the
+    // kernels.  (Pinning the caller's buffers with hipHostRegister for the two copies was dropped for the same
+    // reason: registering costs as much as it saves on a single pass over the data.)
+    auto ensure = [&](int slot, size_t bytes) -> hipError_t {
+        if (bytes <= p->wav_cap[slot]) return hipSuccess;
+        if (p->d_wav[slot]) {
+            hipError_t e = hipFree(p->d_wav[slot]);
+            p->d_wav[slot] = nullptr;
+            p->wav_cap[slot] = 0;
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMalloc(&p->d_wav[slot], bytes);
+        if (e == hipSuccess) p->wav_cap[slot] = bytes;
+        return e;
+    };
+    PIPE_TRY(ensure(0, in_bytes));
+    PIPE_TRY(ensure(1, (size_t)n * 2 * sizeof(float)));
+    PIPE_TRY(ensure(2, (size_t)n * 3 * sizeof(float)));
+    for (int i = 0; i < n_out; ++i) PIPE_TRY(ensure(3 + i, out_bytes));
+    d_pcm = (unsigned char*)p->d_wav[0];
+    d_st = (float*)p->d_wav[1];
+    d_pl = (float*)p->d_wav[2];
+    for (int i = 0; i < n_out; ++i) d_o[i] = (unsigned char*)p->d_wav[3 + i];
     for (auto& e : ev) PIPE_TRY(hipEventCreate(&e));
-    // pinning the caller's buffers lets the copies run at PCIe rate; ignore failures (already pinned / not allowed)
-    const bool pin_in = hipHostRegister(const_cast<void*>(pcm_in), in_bytes, hipHostRegisterDefault) == hipSuccess;
-    bool pin_out[3] = {false, false, false};
-    for (int i = 0; i < n_out; ++i) pin_out[i] = hipHostRegister(outs[i], out_bytes, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
     do {
         hipStream_t st = p->stream;
         if (hipEventRecord(ev[0], st) != hipSuccess) { rc = fail(UPX_ERR_HIP, "event"); break; }
@@ -937,8 +1135,6 @@ int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channel
         if (bad || se != hipSuccess) { rc = fail(UPX_ERR_HIP, "kernel or D2H copy failed: %s", hipGetErrorString(se)); break; }
         for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&p->pipe_ms[i], ev[i], ev[i + 1]);
     } while (0);
-    if (pin_in) (void)hipHostUnregister(const_cast<void*>(pcm_in));
-    for (int i = 0; i < n_out; ++i) if (pin_out[i]) (void)hipHostUnregister(outs[i]);
     cleanup();
 #undef PIPE_TRY
     return rc;

@@ -59,16 +59,23 @@ class DevicePlan:
         if x.ndim != 2 or x.shape[1] != 2:
             raise ValueError("stereo must have shape [T, 2]")
         total = x.shape[0]
-        out = [np.zeros(total, dtype=np.float32) for _ in range(3)]
+        out = [np.empty(total, dtype=np.float32) for _ in range(3)]
         if total == 0:
             return tuple(out)
-        limit = (1 << 29) - 1
-        if total <= limit:
-            _lib.check(self._lib.upx_process(self.handle, _f32p(x), total, *(_f32p(o) for o in out)))
-            return tuple(out)
-        # longer than one launch can index: time-shard on this device (same seam arithmetic as multi-GPU)
-        from .sharding import process_sharded_single_device
-        return process_sharded_single_device(self, x)
+        # any length: the library streams long signals through the device in chunks (upx_process_chunked)
+        _lib.check(self._lib.upx_process(self.handle, _f32p(x), total, *(_f32p(o) for o in out)))
+        return tuple(out)
+
+    def process_chunked(self, stereo: np.ndarray, chunk: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """The same through the streaming pipeline with an explicit chunk length (samples)."""
+        x = np.ascontiguousarray(stereo, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != 2:
+            raise ValueError("stereo must have shape [T, 2]")
+        total = x.shape[0]
+        out = [np.empty(total, dtype=np.float32) for _ in range(3)]
+        if total:
+            _lib.check(self._lib.upx_process_chunked(self.handle, _f32p(x), total, *(_f32p(o) for o in out), int(chunk)))
+        return tuple(out)
 
     # -- device-resident helpers --------------------------------------------
     def alloc(self, nbytes: int) -> int:
