@@ -117,6 +117,9 @@ int upx_process_device(upx_plan* plan, const float* d_stereo, int64_t t_in, int6
 int upx_plan_enable_timing(upx_plan* plan, int enable);
 /* Milliseconds of each band's kernel in the last upx_process_device call (syncs). */
 int upx_plan_band_times_ms(upx_plan* plan, float* ms, int n_bands);
+/* Sum over the last n_calls (<= 64) timed upx_process_device calls, with ONE synchronisation: a timed loop can
+   run back to back and read its kernel times afterwards. */
+int upx_plan_band_times_sum_ms(upx_plan* plan, float* ms, int n_bands, int n_calls);
 /* Kernel symbol name / launch geometry of a band (for profiles and DESIGN.md). */
 int upx_plan_band_info(upx_plan* plan, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,
                        int32_t* blocks_per_stream);

@@ -287,6 +287,7 @@ struct BigImpl {
     static BigEntry get() { return BigEntry{B::N, B::N1, Row::WG, kRowLds, Row::TW_CF, &chunk, &prepare, &fill_n, &fill_rows}; }
 };
 
+constexpr int kTimingSlots = 64;          // recent upx_process_device calls whose per-band events are kept
 constexpr int kMaxFramesPerSample = 64;   // unfused path: ceil(N / hop) frames overlap one sample
 
 const BigEntry* find_big(int log2n) {
@@ -377,7 +378,9 @@ struct BandState {
     int group_size = 1;                 // leader: bands merged into its launch; merged members: 0
     int n_gain = 1;                     // gain slots per bin (merged bands overlap at crossovers)
     int last_wg = 0, last_f = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // current slot of the rings below
+    std::vector<hipEvent_t> ring0, ring1;       // kTimingSlots event pairs: one per recent upx_process_device call
+    std::vector<char> ring_used;
 };
 }   // namespace
 
@@ -389,6 +392,7 @@ struct upx_plan {
     std::map<int, upx::cf*> tw;   // log2n -> device twiddles
     bool timing = false;
     bool timed_once = false;
+    long long timed_calls = 0;      // timed upx_process_device calls since timing was enabled
     unsigned int* d_scalar = nullptr;
     float pipe_ms[3] = {0.f, 0.f, 0.f};
     float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
@@ -576,8 +580,15 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             const size_t need = (size_t)s.chunk_frames * s.n * 5 / 2;   // z + y + yc/2
             if (need > p->scratch_cf) p->scratch_cf = need;
         }
-        HIP_TRY(hipEventCreate(&s.ev0));
-        HIP_TRY(hipEventCreate(&s.ev1));
+        s.ring0.assign(kTimingSlots, nullptr);
+        s.ring1.assign(kTimingSlots, nullptr);
+        s.ring_used.assign(kTimingSlots, 0);
+        for (int i = 0; i < kTimingSlots; ++i) {
+            HIP_TRY(hipEventCreate(&s.ring0[i]));
+            HIP_TRY(hipEventCreate(&s.ring1[i]));
+        }
+        s.ev0 = s.ring0[0];
+        s.ev1 = s.ring1[0];
         off_w += s.n;
         off_g += nb;
     }
@@ -621,8 +632,8 @@ void upx_plan_destroy(upx_plan* p) {
         if (s.d_ws) (void)hipFree(s.d_ws);
         if (s.d_gain) (void)hipFree(s.d_gain);
         if (s.d_tw_n) (void)hipFree(s.d_tw_n);
-        if (s.ev0) (void)hipEventDestroy(s.ev0);
-        if (s.ev1) (void)hipEventDestroy(s.ev1);
+        for (auto e : s.ring0) if (e) (void)hipEventDestroy(e);
+        for (auto e : s.ring1) if (e) (void)hipEventDestroy(e);
     }
     for (auto& kv : p->tw) (void)hipFree(kv.second);
     if (p->d_scalar) (void)hipFree(p->d_scalar);
@@ -700,9 +711,13 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         for (auto& s : p->bands) s.last_wg = 0;
         return UPX_OK;
     }
+    const int slot = (int)(p->timed_calls % kTimingSlots);
     for (size_t b = 0; b < p->bands.size(); ++b) {
         BandState& s = p->bands[b];
         s.last_wg = 0;
+        s.ev0 = s.ring0[slot];
+        s.ev1 = s.ring1[slot];
+        s.ring_used[slot] = 0;
         if (s.group_size == 0) continue;                              // carried by its group leader's launch
         const long long j_hi = (own_len + s.hop - 1) / s.hop;       // frames with j*hop < own_len
         const long long m_all = (t_out + s.hop - 1) / s.hop;        // hop-blocks that intersect [0, t_out)
@@ -786,6 +801,10 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
     }
     HIP_TRY(hipGetLastError());
     p->timed_once = p->timing;
+    if (p->timing) {
+        for (auto& s : p->bands) s.ring_used[slot] = s.last_wg > 0;
+        p->timed_calls += 1;
+    }
     return UPX_OK;
 }
 
@@ -993,6 +1012,7 @@ int upx_process(upx_plan* p, const float* stereo, int64_t n, float* out_c, float
 int upx_plan_enable_timing(upx_plan* p, int enable) {
     if (!p) return fail(UPX_ERR_INVALID, "upx_plan_enable_timing: NULL plan");
     p->timing = enable != 0;
+    p->timed_calls = 0;
     if (!p->timing) p->timed_once = false;
     return UPX_OK;
 }
@@ -1004,6 +1024,25 @@ int upx_plan_band_times_ms(upx_plan* p, float* ms, int n_bands) {
     for (int b = 0; b < n_bands; ++b) {
         ms[b] = 0.f;
         if (p->bands[b].last_wg > 0) HIP_TRY(hipEventElapsedTime(&ms[b], p->bands[b].ev0, p->bands[b].ev1));
+    }
+    return UPX_OK;
+}
+
+int upx_plan_band_times_sum_ms(upx_plan* p, float* ms, int n_bands, int n_calls) {
+    if (!p || !ms || n_bands != (int)p->bands.size() || n_calls < 1 || n_calls > kTimingSlots)
+        return fail(UPX_ERR_INVALID, "upx_plan_band_times_sum_ms: bad argument (at most %d calls are kept)", kTimingSlots);
+    if ((long long)n_calls > p->timed_calls) return fail(UPX_ERR_INVALID, "only %lld timed calls recorded", p->timed_calls);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int b = 0; b < n_bands; ++b) {
+        double sum = 0.0;
+        for (long long c = p->timed_calls - n_calls; c < p->timed_calls; ++c) {
+            const int slot = (int)(c % kTimingSlots);
+            if (!p->bands[b].ring_used[slot]) continue;
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, p->bands[b].ring0[slot], p->bands[b].ring1[slot]));
+            sum += t;
+        }
+        ms[b] = (float)sum;
     }
     return UPX_OK;
 }

@@ -112,6 +112,12 @@ class DevicePlan:
         _lib.check(self._lib.upx_plan_band_times_ms(self.handle, _f32p(ms), self.n_bands))
         return ms
 
+    def band_times_sum_ms(self, n_calls: int) -> np.ndarray:
+        """Per-band kernel time summed over the last n_calls (<= 64) timed process_device calls; one sync."""
+        ms = np.zeros(self.n_bands, dtype=np.float32)
+        _lib.check(self._lib.upx_plan_band_times_sum_ms(self.handle, _f32p(ms), self.n_bands, int(n_calls)))
+        return ms
+
     def band_info(self, band: int) -> dict:
         v = [C.c_int32() for _ in range(4)]
         _lib.check(self._lib.upx_plan_band_info(self.handle, int(band), *(C.byref(i) for i in v)))
