@@ -507,3 +507,34 @@ def test_streamed_host_call(ux, orc, monkeypatch):
         for u, v in zip(one, got):
             assert u.shape == v.shape == (total,) and float(np.max(np.abs(u - v))) < 1e-6, total
     plan.close()
+
+
+def test_signal_longer_than_one_launch(ux, orc):
+    """More than 2^29 samples (a launch's 32-bit byte offsets end there): upx_process streams the signal through
+    the device in chunks, so the length is bounded by host memory only.  Oracle windows at the start, across the
+    2^29 boundary and at the ragged end."""
+    try:
+        import psutil
+        if psutil.virtual_memory().available < 40 * (1 << 30):
+            pytest.skip("needs ~12 GB of host memory")
+    except ImportError:
+        pass
+    total = (1 << 29) + 12345
+    base = orc.synthetic_stereo(1 << 22, 41)
+    x = np.tile(base, (total // len(base) + 1, 1))[:total]
+    x *= np.linspace(0.2, 1.0, total, dtype=np.float32)[:, None]   # no two windows alike
+    bands = gpu_chain(ux, [0, 300, 3000], 48000, 4096, 64)
+    ref_bands = orc.plan_bands([0, 300, 3000], 0.75, orc.win_blackman_harris, 48000, max_block_size=4096, threshold_factor=64)
+    got = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, bands)
+    assert all(g.shape == (total,) for g in got)
+    span, pad = 60000, 8192    # slice starts on the frame grid of every band; compare what lies a frame inside it
+    for start in (0, (1 << 29) - 40960, total - span):
+        s0 = max(0, (start - pad) // 4096 * 4096)
+        sl = x[s0:min(total, s0 + span + 2 * pad)]
+        ref = orc.extract_multi_band(sl[:, 0].astype(np.float64), sl[:, 1].astype(np.float64), ref_bands)
+        lo = 0 if s0 == 0 else pad
+        hi = len(sl) if s0 + len(sl) == total else len(sl) - pad
+        for g, r in zip(got, ref):
+            close(g[s0 + lo:s0 + hi], r[lo:hi].astype(np.float32))
+    for g in got:
+        assert np.all(np.isfinite(g[::4099]))
