@@ -266,12 +266,11 @@ struct BigImpl {
             hipLaunchKernelGGL(upx_big_frame_kernel<B>, dim3(row_wgs(ch)), dim3(Row::WG), kRowLds, st, a);
         }
         hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks(upx::big_mask_threads<B>(ch / 2))), dim3(256), 0, st, a);
-        rows(a.y, a.tw_rows, ch * B::N1, st);
-        rows(a.yc, a.tw_rows, (ch / 2) * B::N1, st);
-        if (B::N1 == 16) {
-            hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a.y, a.tw_n, ch);
-            hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)(ch / 2) * B::N2)), dim3(256), 0, st, a.yc, a.tw_n, ch / 2);
-        }
+        // y (ch frames) and yc (ch/2 frames) are adjacent in the scratch: one launch covers both
+        const int inv_frames = ch + ch / 2;
+        rows(a.y, a.tw_rows, inv_frames * B::N1, st);
+        if (B::N1 == 16)
+            hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)inv_frames * B::N2)), dim3(256), 0, st, a.y, a.tw_n, inv_frames);
         hipLaunchKernelGGL(upx_big_ola_kernel<B>, dim3(blocks((long long)(a.m1 - a.m0) * a.hop)), dim3(256), 0, st, a);
     }
     static int prepare() {
