@@ -13,11 +13,17 @@
 // the overlap-add of :392-407 / framing of :426-472 in closed form
 // (SURVEY.md section 3.3).
 //
+// Streams of N <= 2048 run a plain Stockham schedule (Cfg); N = 4096 and 8192 span
+// several waves and are routed so that all exchanges but one per transform stay
+// inside a wave (WideCfg, below).
+//
 // The body is written against an executor `Ex` whose `each(f)` runs `f` for
-// every thread of the workgroup and then barriers.  On the GPU that is the
-// thread itself + s_barrier; tests/emu instantiates the SAME code with a
-// sequential executor on the host to check indexing without a GPU (test
-// infrastructure only - nothing in the product path runs on the CPU).
+// every thread of the workgroup and then synchronises: a wave-level fence when
+// the data exchanged stays inside a wave, s_barrier otherwise (`wg_barrier()`
+// where a wide stream's waves meet).  tests/emu instantiates the SAME code with
+// sequential executors on the host to check indexing and barrier placement
+// without a GPU (test infrastructure only - nothing in the product path runs on
+// the CPU).
 #pragma once
 #include <stdint.h>
 
@@ -543,6 +549,11 @@ struct Stream {
 //   tailLR(a) read, final pass, window, overlap-add, emit hop; then head(b) ...
 //   tailLR(b), then stage the centre pair | mirror -> lower region | inv0 ... mid
 //   tailC is merged into the next iteration's head(a).
+// Wide streams (C::WIDE): head = load, window, radix-16 over n1, * W_N^(k1 n2), transposed write | B1 |
+//   sub-FFT passes, mask and inverse sub-FFT passes with wave-level ordering only, * W_N^(k1 n2) | B2 |
+//   tail = column read, radix-16 over k1, window, overlap-add;  | B3 | before the centre pair is staged.
+// Loads are placed for latency, not where they are used: gains one phase before the mask, the frame's
+// re-read samples at the top of the phase that ends the previous inverse, the new hop one frame ahead.
 // ---------------------------------------------------------------------------
 template <class C, class Ex>
 UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
