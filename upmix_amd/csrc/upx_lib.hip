@@ -568,8 +568,11 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         }
         s.d_tw = it->second;
         if (s.big) {
-            // chunks of ~4M complex per scratch buffer (32 MB: stays in L2 / Infinity Cache)
-            s.chunk_frames = (1 << 22) / s.n;
+            // frames per chunk: 2^24 complex per scratch buffer (128 MB; z + y + yc = 320 MB).  Measured on the
+            // default plan: 2^21 10.2 ms, 2^22 7.9, 2^23 7.0, 2^24 6.7, 2^25 8.3 - below, the 7 launches per chunk
+            // (10-19 us each) are too short; above, the scratch falls out of the Infinity Cache altogether.
+            const char* cl = std::getenv("UPX_BIG_CHUNK_LOG2");
+            s.chunk_frames = (1 << (cl ? std::atoi(cl) : 24)) / s.n;
             if (s.chunk_frames < 2 * s.k + 4) s.chunk_frames = 2 * s.k + 4;
             s.chunk_frames += s.chunk_frames & 1;
             std::vector<upx::cf> host((size_t)s.n);
