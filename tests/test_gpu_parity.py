@@ -538,3 +538,24 @@ def test_signal_longer_than_one_launch(ux, orc):
             close(g[s0 + lo:s0 + hi], r[lo:hi].astype(np.float32))
     for g in got:
         assert np.all(np.isfinite(g[::4099]))
+
+
+def test_c4_plan_96k_prefix_vs_oracle(ux, orc):
+    """BASELINE configs[3] plan: 96 kHz, same edges -> STFT [8192 x4, 2048, 512], 2 s prefix, seed 3,
+    whole and cut into two time shards on one device (the multi-GPU arithmetic without RCCL)."""
+    from upmix_amd import sharding
+    sr, edges = 96000, [0, 30, 120, 480, 1920, 7680]
+    x = orc.synthetic_stereo(2 * sr, 3)
+    bands = gpu_chain(ux, edges, sr, 8192, 32)
+    ob = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, sr, max_block_size=8192, threshold_factor=32)
+    assert [b.block_size for b in bands] == [8192, 8192, 8192, 8192, 2048, 512]
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+    whole = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], sr, bands)
+    for got, r in zip(whole, ref):
+        close(got, r)
+    plan = ux.DevicePlan(bands)
+    sharded = sharding.process_sharded_single_device(plan, x, max_shard=len(x) // 2 + 1)
+    for got, r, w in zip(sharded, ref, whole):
+        close(got, r)
+        assert float(np.max(np.abs(got - w))) < 1e-6
+    plan.close()
