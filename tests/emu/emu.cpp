@@ -139,6 +139,12 @@ int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch_max) {
     std::vector<upx::cf> lds((size_t)Row::LDS_CF);
     a.tw_n = tw_n.data(); a.tw_rows = tw_rows.data();
     a.z = z.data(); a.y = y.data(); a.yc = yc.data();
+    // the gain rows in the order the kernels read them (the library does the same at plan creation)
+    std::vector<float> gain_perm((size_t)a.n_gain * a.gain_stride);
+    for (int q = 0; q < a.n_gain; ++q)
+        for (int i = 0; i <= B::N / 2; ++i)
+            gain_perm[(size_t)q * a.gain_stride + i] = a.gain[(size_t)q * a.gain_stride + upx::big_gain_bin<B>(i)];
+    a.gain = gain_perm.data();
     a.ch = ch;
     auto rows = [&](upx::cf* buf, int n_rows) {
         for (int wg = 0; wg < (n_rows + Row::G - 1) / Row::G; ++wg) {
@@ -155,7 +161,6 @@ int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch_max) {
         for (auto& v : z) v = upx::mk(NAN, NAN);
         if (B::N1 == 16) {
             for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step1_audio<B>(a, g);
-            rows(a.z, ch * 16);
         } else {
             for (int wg = 0; wg < (ch + Row::G - 1) / Row::G; ++wg) {
                 SeqExec<Row::P> ex;
@@ -164,9 +169,20 @@ int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch_max) {
                 upx::big_frame_program<B>(ex, a, lds.data(), wg);
             }
         }
-        for (long long g = 0; g < upx::big_mask_threads<B>(ch / 2); ++g) upx::big_mask<B>(a, g);
-        rows(a.y, ch * B::N1);
-        rows(a.yc, (ch / 2) * B::N1);
+        if constexpr (B::N1 == 16) {
+            // rows -> mask -> rows fused: one workgroup per (frame pair, mirror pair of rows)
+            std::vector<upx::cf> lds2((size_t)(2 * Row::PITCH + Row::TW_CF));
+            for (int wg = 0; wg < (ch / 2) * 8; ++wg) {
+                SeqExec<Row::P> ex;
+                ex.st.resize(2 * Row::LANES);
+                for (auto& v : lds2) v = upx::mk(NAN, NAN);
+                upx::big_mid_program<B>(ex, a, lds2.data(), wg);
+            }
+        } else {
+            for (long long g = 0; g < upx::big_mask_threads<B>(ch / 2); ++g) upx::big_mask<B>(a, g);
+            rows(a.y, ch * B::N1);
+            rows(a.yc, (ch / 2) * B::N1);
+        }
         if (B::N1 == 16) {
             for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step2_inv<B>(a.y, a.tw_n, ch, g);
             for (long long g = 0; g < (long long)(ch / 2) * B::N2; ++g) upx::big_step2_inv<B>(a.yc, a.tw_n, ch / 2, g);

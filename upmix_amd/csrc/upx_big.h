@@ -227,6 +227,185 @@ UPX_HD void big_mask(const BigArgs& a, long long gid) {
     if (!self) a.yc[fc + om] = cswap(cm);
 }
 
+// ---- N1 == 16: rows -> mask -> rows in ONE kernel --------------------------------------------------
+// A workgroup takes one frame pair and one mirror pair of rows, k1 and 16 - k1 (0 and 8 for unit 0): two row
+// streams of N2/16 lanes each.  Bin k = k1 + 16 k2 and its mirror N - k = (16 - k1) + 16 (N2 - 1 - k2) (k1 = 0:
+// (0, N2 - k2)) then sit in the two LDS row buffers of the same workgroup, so the forward row transforms, the L/R
+// split + mask and the inverse row transforms of Ls + i Rs (both frames) and Ca + i Cb (the pair) run back to back
+// without the spectra leaving the CU: z is read once, y and yc are written once (2.5 of the 7.5 passes over the
+// scratch that separate rows / mask / rows kernels make).  The layout inside a row stream is the one of the wide
+// streams of upx_core.h (own bins in slots s < 8, mirrors in the partner's upper slots, rewritten in place).
+// The per-bin gain rows are read in the order (row r = 2 unit + stream, slot s, lane): big_gain_bin().
+template <class B>
+inline int big_gain_bin(int i) {
+    constexpr int L = B::Row::LANES;
+    if (B::N1 == 1 || i >= B::N / 2) return i;
+    const int sl = i % L, s = (i / L) % 8, r = i / (8 * L);
+    return wide_k1_of_sub(r) + 16 * (sl + L * s);
+}
+
+template <class B, class Ex>
+UPX_HD void big_mid_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index) {
+    using C = typename B::Row;
+    using S = Stream<C>;
+    using PS = typename C::PS;
+    using Thread = ThreadT<C::P>;
+    constexpr int L = C::LANES, P = C::P, H = P / 2, SP = C::SPITCH, BUF = C::PITCH, N = B::N, N2 = B::N2;
+    constexpr int LAST = PS::n - 1;
+    static_assert(P == 16 && B::N1 == 16, "fused rows/mask/rows needs 16 points per lane and the 16 x N2 layout");
+    cf* const tw = lds_all + 2 * BUF;
+    const int pp = wg_index / 8, unit = wg_index % 8;   // frame pair of the chunk, mirror pair of rows
+    ex.each([&](int tid, Thread&) {
+        for (int i = tid; i < C::TW_CF; i += 2 * L) tw[i] = a.tw_rows[i];
+    });
+    // per thread: row stream g, lane sl, row k1; the partner cells (see mirror_of in upx_core.h)
+    auto row_of = [&](int tid) { return wide_k1_of_sub(2 * unit + tid / L); };
+    auto partner = [&](int tid) {
+        const int g = tid / L, sl = tid % L;
+        const int gp = unit ? (g ^ 1) : g;
+        return lds_all + gp * BUF + padp<P>((H + 1) * L - (row_of(tid) ? 1 : 0) - sl);
+    };
+    auto load_row = [&](int tid, Thread& th, const cf* frame) {
+        const cf* data = frame + (size_t)row_of(tid) * N2 + tid % L;
+#pragma unroll
+        for (int s = 0; s < P; ++s) th.x[s] = data[s * L];
+        S::template pass_compute<0>(th, tw, tid % L);
+    };
+    auto scatter0 = [&](int tid, Thread& th) { S::template pass_write<0>(th, lds_all + (tid / L) * BUF, tid % L); };
+    auto mids = [&]() { S::template mid_passes<1>(ex, lds_all, tw); };
+    auto last_pass = [&](int tid, Thread& th) { S::template read_compute<LAST>(th, lds_all + (tid / L) * BUF, tw, tid % L); };
+    auto store_row = [&](int tid, Thread& th, cf* frame) {
+        cf* data = frame + (size_t)row_of(tid) * N2 + tid % L;
+#pragma unroll
+        for (int s = 0; s < P; ++s) data[s * L] = th.x[s];
+    };
+    // inverse row transform of what the mask / stage step left: own slots in registers, upper slots in LDS
+    auto inverse_to = [&](cf* frame) {
+        ex.each2(
+            [&](int tid, Thread& th) {
+                const cf* b = lds_all + (tid / L) * BUF + padp<P>(tid % L);
+#pragma unroll
+                for (int s = H; s < P; ++s) th.x[s] = lds_load(b + s * SP);
+                S::template pass_compute<0>(th, tw, tid % L);
+            },
+            scatter0);
+        mids();
+        ex.each([&](int tid, Thread& th) {
+            last_pass(tid, th);
+            store_row(tid, th, frame);
+        });
+    };
+    const bool pair_ok = pp < a.ch / 2;   // (grid is exact; kept for safety with padded grids)
+    for (int half = 0; half < 2 && pair_ok; ++half) {
+        cf* const zf = a.z + (size_t)(2 * pp + half) * N;
+        cf* const yf = a.y + (size_t)(2 * pp + half) * N;
+        ex.each2(
+            [&](int tid, Thread& th) {
+                // the gain rows of the own bins first: their latency hides behind the row transform
+                const int lane = (2 * unit + tid / L) * 8 * L + tid % L;
+#pragma unroll
+                for (int s = 0; s < H; ++s) {
+                    th.g0[s] = a.gain[lane + s * L];
+                    th.g1[s] = a.n_gain > 1 ? a.gain[a.gain_stride + lane + s * L] : 0.f;
+                }
+                th.gn[0] = a.gain[N / 2];
+                th.gn[1] = a.n_gain > 1 ? a.gain[a.gain_stride + N / 2] : 0.f;
+                load_row(tid, th, zf);
+            },
+            scatter0);
+        mids();
+        ex.each2(last_pass, [&](int tid, Thread& th) {
+            cf* b = lds_all + (tid / L) * BUF + padp<P>(tid % L);
+#pragma unroll
+            for (int s = H; s < P; ++s) b[s * SP] = th.x[s];   // park the upper slots for the partners
+        });
+        ex.each([&](int tid, Thread& th) {
+            const bool first = unit == 0 && tid == 0;   // holds DC (slot 0) and Nyquist (slot H) of the frame
+            cf* const part = partner(tid);
+            cf* const nyq = lds_all + H * SP;
+            const int lane = (2 * unit + tid / L) * 8 * L + tid % L;
+            cf nyq_y = mk(0.f, 0.f);
+            float nyq_c = 0.f;
+            if (first) {
+                const cf z = th.x[H];
+                cf cn = mk(0.f, 0.f), lsn = cn, rsn = cn;
+                for (int q = 0; q < a.n_gain; ++q) {
+                    const float g2 = q < 2 ? th.gn[q] : a.gain[q * a.gain_stride + N / 2];
+                    if (g2 != 0.f) {
+                        cf l = mk(g2 * (z.x + z.x), 0.f), r = mk(g2 * (z.y + z.y), 0.f), c, ls, rs;
+                        mask_bin(l, r, c, ls, rs);
+                        cn = cn + c; lsn = lsn + ls; rsn = rsn + rs;
+                    }
+                }
+                nyq_y = mk(lsn.x, rsn.x);
+                nyq_c = cn.x;
+            }
+            cf zpart[H];
+#pragma unroll
+            for (int s = 0; s < H; ++s) zpart[s] = lds_load(part + (H - 1 - s) * SP);
+#pragma unroll
+            for (int s = 0; s < H; ++s) {
+                const bool dc = s == 0 && first;
+                const cf za = th.x[s];
+                const cf zb = dc ? za : zpart[s];
+                const cf l0 = add_conj(za, zb), r0 = mi_sub_conj(za, zb);
+                cf c = mk(0.f, 0.f), ls = c, rs = c;
+                auto add_band = [&](float g2) {
+                    if (g2 != 0.f) {
+                        cf l = scale(l0, g2), r = scale(r0, g2), cq, lq, rq;
+                        mask_bin(l, r, cq, lq, rq);
+                        c = c + cq; ls = ls + lq; rs = rs + rq;
+                    }
+                };
+                add_band(th.g0[s]);
+                if (a.n_gain > 1) {
+                    add_band(th.g1[s]);
+                    for (int q = 2; q < a.n_gain; ++q) add_band(a.gain[q * a.gain_stride + lane + s * L]);
+                }
+                th.x[s] = swap_add_i(ls, rs);
+                const cf ym = swap_conj_add_i(ls, rs);
+                if (s == 0) {
+                    cf* dst = first ? nyq : part + (H - 1) * SP;
+                    *dst = first ? cswap(nyq_y) : ym;
+                } else {
+                    part[(H - 1 - s) * SP] = ym;
+                }
+                const cf cv = dc ? mk(c.x, nyq_c) : c;
+                if (half == 0) {
+                    th.cs[s] = cv;
+                } else {
+                    const cf ca = th.cs[s], cb = cv;
+                    cf ck = swap_add_i(ca, cb), cm = swap_conj_add_i(ca, cb);
+                    if (dc) {
+                        ck = mk(cb.x, ca.x);
+                        cm = mk(cb.y, ca.y);
+                    }
+                    th.cs[s] = ck;
+                    th.part[s] = cm;
+                }
+            }
+        });
+        inverse_to(yf);
+    }
+    if (pair_ok) {
+        ex.each([&](int tid, Thread& th) {
+            const bool first = unit == 0 && tid == 0;
+            cf* const part = partner(tid);
+#pragma unroll
+            for (int s = 0; s < H; ++s) {
+                th.x[s] = th.cs[s];
+                if (s == 0) {
+                    cf* dst = first ? lds_all + H * SP : part + (H - 1) * SP;
+                    *dst = th.part[0];
+                } else {
+                    part[(H - 1 - s) * SP] = th.part[s];
+                }
+            }
+        });
+        inverse_to(a.yc + (size_t)pp * N);
+    }
+}
+
 // ---- overlap-add of the chunk's frames into the output planes; one thread per sample -------
 template <class B>
 UPX_HD void big_ola(const BigArgs& a, long long gid) {

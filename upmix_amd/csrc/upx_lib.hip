@@ -214,6 +214,15 @@ __global__ __launch_bounds__(B::Row::WG) void upx_big_frame_kernel(upx::BigArgs 
     DevExec<B::Row::WAVE_SYNC, B::Row::P> ex;
     upx::big_frame_program<B>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
+// rows -> mask -> rows of one frame pair and one mirror pair of rows (N1 == 16); two row streams per workgroup
+template <class B>
+__global__ __launch_bounds__(2 * B::Row::LANES) void upx_big_mid_kernel(upx::BigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (B::N1 == 16) {
+        DevExec<false, B::Row::P> ex;
+        upx::big_mid_program<B>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    }
+}
 template <class B>
 __global__ __launch_bounds__(256) void upx_big_mask_kernel(upx::BigArgs a) {
     upx::big_mask<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(256) void upx_big_ola_kernel(upx::BigArgs a) {
 }
 
 struct BigEntry {
+    int (*gain_bin)(int);   // order of the per-bin gain rows as the kernels read them
     int n, n1, row_wg, row_lds, row_tw_cf;
     void (*chunk)(const upx::BigArgs&, hipStream_t);
     int (*prepare)();
@@ -251,6 +261,7 @@ template <class B>
 struct BigImpl {
     using Row = typename B::Row;
     static constexpr int kRowLds = Row::LDS_CF * (int)sizeof(upx::cf);
+    static constexpr int kMidLds = (2 * Row::PITCH + Row::TW_CF) * (int)sizeof(upx::cf);
     static unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
     static unsigned row_wgs(int rows) { return (unsigned)((rows + Row::G - 1) / Row::G); }
     static void rows(upx::cf* buf, const upx::cf* tw, int n_rows, hipStream_t st) {
@@ -259,16 +270,17 @@ struct BigImpl {
     // all launches of one chunk, in stream order
     static void chunk(const upx::BigArgs& a, hipStream_t st) {
         const int ch = a.ch;
-        if (B::N1 == 16) {
-            hipLaunchKernelGGL(upx_big_step1_audio_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a);
-            rows(a.z, a.tw_rows, ch * 16, st);
-        } else {
-            hipLaunchKernelGGL(upx_big_frame_kernel<B>, dim3(row_wgs(ch)), dim3(Row::WG), kRowLds, st, a);
-        }
-        hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks(upx::big_mask_threads<B>(ch / 2))), dim3(256), 0, st, a);
         // y (ch frames) and yc (ch/2 frames) are adjacent in the scratch: one launch covers both
         const int inv_frames = ch + ch / 2;
-        rows(a.y, a.tw_rows, inv_frames * B::N1, st);
+        if (B::N1 == 16) {
+            hipLaunchKernelGGL(upx_big_step1_audio_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a);
+            // row transforms, mask and inverse row transforms fused: one workgroup per (frame pair, mirror pair of rows)
+            hipLaunchKernelGGL(upx_big_mid_kernel<B>, dim3((unsigned)(ch / 2) * 8), dim3(2 * Row::LANES), kMidLds, st, a);
+        } else {
+            hipLaunchKernelGGL(upx_big_frame_kernel<B>, dim3(row_wgs(ch)), dim3(Row::WG), kRowLds, st, a);
+            hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks(upx::big_mask_threads<B>(ch / 2))), dim3(256), 0, st, a);
+            rows(a.y, a.tw_rows, inv_frames * B::N1, st);
+        }
         if (B::N1 == 16)
             hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)inv_frames * B::N2)), dim3(256), 0, st, a.y, a.tw_n, inv_frames);
         hipLaunchKernelGGL(upx_big_ola_kernel<B>, dim3(blocks((long long)(a.m1 - a.m0) * a.hop)), dim3(256), 0, st, a);
@@ -279,11 +291,16 @@ struct BigImpl {
         if (!e && B::N1 == 1)
             e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_frame_kernel<B>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kRowLds);
+        if (!e && B::N1 == 16)
+            e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_mid_kernel<B>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kMidLds);
         return e;
     }
     static void fill_n(upx::cf* tw) { if (B::N1 == 16) upx::fill_big_twiddles<B>(tw, turn_trig); }
     static void fill_rows(upx::cf* tw) { upx::fill_twiddles<Row>(tw, turn_trig); }
-    static BigEntry get() { return BigEntry{B::N, B::N1, Row::WG, kRowLds, Row::TW_CF, &chunk, &prepare, &fill_n, &fill_rows}; }
+    static BigEntry get() {
+        return BigEntry{&upx::big_gain_bin<B>, B::N, B::N1, Row::WG, kRowLds, Row::TW_CF, &chunk, &prepare, &fill_n, &fill_rows};
+    }
 };
 
 constexpr int kTimingSlots = 64;          // recent upx_process_device calls whose per-band events are kept
@@ -611,11 +628,12 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                 const float g = gain[band_gain_off[m] + k];
                 if (g != 0.f) table[(size_t)count[k]++ * nb + k] = 0.5f * g;
             }
-        if (s.kern) {
-            // rows in the order the kernel's threads read them (natural for plain streams)
+        {
+            // rows in the order the kernel's threads read them (natural for plain streams and whole-frame rows)
+            int (*order)(int) = s.kern ? s.kern->gain_bin : s.big->gain_bin;
             std::vector<float> natural(table);
             for (int q = 0; q < slots; ++q)
-                for (int i = 0; i < nb; ++i) table[(size_t)q * nb + i] = natural[(size_t)q * nb + s.kern->gain_bin(i)];
+                for (int i = 0; i < nb; ++i) table[(size_t)q * nb + i] = natural[(size_t)q * nb + order(i)];
         }
         s.n_gain = slots;
         HIP_TRY(hipMalloc(&s.d_gain, table.size() * sizeof(float)));
