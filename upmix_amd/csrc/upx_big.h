@@ -10,8 +10,9 @@
 // transposed (decimation-in-time) order on that same layout,
 //     rows (FFT_N2 over k2 of row k1)  ->  x[n1 N2 + n2] = sum_k1 W_16^(k1 n1) W_N^(k1 n2) row_k1[n2]
 // and therefore end in NATURAL time order: every kernel reads and writes coalesced.
-// Frames are processed in chunks of CH frames (scratch stays L2/MALL resident):
-//     step1(audio*w_A) -> rows -> mask -> rows,step2 on Ls+iRs -> rows,step2 on Ca+iCb -> overlap-add
+// Frames are processed in chunks of CH frames:
+//     step1(audio*w_A) -> [rows -> mask -> rows of Ls+iRs and Ca+iCb] -> step2 -> overlap-add
+// (the bracket is one kernel, big_mid_program, when N1 = 16; three kernels when the frame is a single row)
 // with the same conventions as the fused kernel (upx_core.h): frame pairs
 // (odd j, j+1) share one centre transform, inverse by re/im swap, contributions
 // added in increasing j in float32, bands summed in list order.
