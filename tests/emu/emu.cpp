@@ -159,8 +159,23 @@ int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch_max) {
         a.m0 = m0;
         a.m1 = m0 + emit < m_hi ? m0 + emit : m_hi;
         for (auto& v : z) v = upx::mk(NAN, NAN);
-        if (B::N1 == 16) {
-            for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step1_audio<B>(a, g);
+        // the library's choice: N = 16 384 holds the whole frame in one workgroup (steps 1 and 2 inside the fused
+        // kernel), 32 768 / 65 536 take one mirror pair of rows per workgroup between separate step kernels
+        constexpr int kMidRows = (B::N1 == 16 && 16 * Row::LANES == B::N2 && (16 * Row::PITCH + Row::TW_CF) * 8 <= 160 * 1024) ? 16 : 2;
+        if constexpr (B::N1 == 16) {
+            if (kMidRows == 2)
+                for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step1_audio<B>(a, g);
+            std::vector<upx::cf> lds2((size_t)(kMidRows * Row::PITCH + Row::TW_CF));
+            for (int wg = 0; wg < (ch / 2) * (kMidRows == 2 ? 8 : 1); ++wg) {
+                SeqExec<Row::P> ex;
+                ex.st.resize(kMidRows * Row::LANES);
+                for (auto& v : lds2) v = upx::mk(NAN, NAN);
+                upx::big_mid_program<B, kMidRows>(ex, a, lds2.data(), wg);
+            }
+            if (kMidRows == 2) {
+                for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step2_inv<B>(a.y, a.tw_n, ch, g);
+                for (long long g = 0; g < (long long)(ch / 2) * B::N2; ++g) upx::big_step2_inv<B>(a.yc, a.tw_n, ch / 2, g);
+            }
         } else {
             for (int wg = 0; wg < (ch + Row::G - 1) / Row::G; ++wg) {
                 SeqExec<Row::P> ex;
@@ -168,24 +183,9 @@ int run_big(upx::BigArgs a, int m_lo, int m_hi, int ch_max) {
                 for (auto& v : lds) v = upx::mk(NAN, NAN);
                 upx::big_frame_program<B>(ex, a, lds.data(), wg);
             }
-        }
-        if constexpr (B::N1 == 16) {
-            // rows -> mask -> rows fused: one workgroup per (frame pair, mirror pair of rows)
-            std::vector<upx::cf> lds2((size_t)(2 * Row::PITCH + Row::TW_CF));
-            for (int wg = 0; wg < (ch / 2) * 8; ++wg) {
-                SeqExec<Row::P> ex;
-                ex.st.resize(2 * Row::LANES);
-                for (auto& v : lds2) v = upx::mk(NAN, NAN);
-                upx::big_mid_program<B>(ex, a, lds2.data(), wg);
-            }
-        } else {
             for (long long g = 0; g < upx::big_mask_threads<B>(ch / 2); ++g) upx::big_mask<B>(a, g);
             rows(a.y, ch * B::N1);
             rows(a.yc, (ch / 2) * B::N1);
-        }
-        if (B::N1 == 16) {
-            for (long long g = 0; g < (long long)ch * B::N2; ++g) upx::big_step2_inv<B>(a.y, a.tw_n, ch, g);
-            for (long long g = 0; g < (long long)(ch / 2) * B::N2; ++g) upx::big_step2_inv<B>(a.yc, a.tw_n, ch / 2, g);
         }
         for (long long g = 0; g < (long long)(a.m1 - a.m0) * a.hop; ++g) upx::big_ola<B>(a, g);
     }

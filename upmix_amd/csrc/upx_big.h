@@ -245,7 +245,12 @@ inline int big_gain_bin(int i) {
     return wide_k1_of_sub(r) + 16 * (sl + L * s);
 }
 
-template <class B, class Ex>
+// ROWS = 2: the workgroup described above (rows come from / go to the scratch).
+// ROWS = 16 (N = 16 384 only, where a frame's sixteen 1024-point rows fit one workgroup's LDS): the workgroup holds
+// the WHOLE frame, so step 1 (window, radix-16 over n1, twiddle, transposed write into the row buffers) and step 2
+// (column read, twiddle, radix-16 over k1) run in registers at its two ends, exactly like the cross-wave phases of a
+// wide stream: audio in, time-domain y / yc out, no z at all (3 passes over the scratch instead of 8).
+template <class B, int ROWS, class Ex>
 UPX_HD void big_mid_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index) {
     using C = typename B::Row;
     using S = Stream<C>;
@@ -253,34 +258,81 @@ UPX_HD void big_mid_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index)
     using Thread = ThreadT<C::P>;
     constexpr int L = C::LANES, P = C::P, H = P / 2, SP = C::SPITCH, BUF = C::PITCH, N = B::N, N2 = B::N2;
     constexpr int LAST = PS::n - 1;
+    constexpr int THREADS = ROWS * L;
+    constexpr bool WHOLE = ROWS == 16;
     static_assert(P == 16 && B::N1 == 16, "fused rows/mask/rows needs 16 points per lane and the 16 x N2 layout");
-    cf* const tw = lds_all + 2 * BUF;
-    const int pp = wg_index / 8, unit = wg_index % 8;   // frame pair of the chunk, mirror pair of rows
+    static_assert(ROWS == 2 || (ROWS == 16 && THREADS == N2), "two rows, or the whole frame with one lane per n2");
+    cf* const tw = lds_all + ROWS * BUF;
+    const int pp = WHOLE ? wg_index : wg_index / 8;   // frame pair of the chunk
+    const int unit = WHOLE ? 0 : wg_index % 8;        // ROWS == 2: which mirror pair of rows
     ex.each([&](int tid, Thread&) {
-        for (int i = tid; i < C::TW_CF; i += 2 * L) tw[i] = a.tw_rows[i];
+        for (int i = tid; i < C::TW_CF; i += THREADS) tw[i] = a.tw_rows[i];
     });
-    // per thread: row stream g, lane sl, row k1; the partner cells (see mirror_of in upx_core.h)
-    auto row_of = [&](int tid) { return wide_k1_of_sub(2 * unit + tid / L); };
-    auto partner = [&](int tid) {
+    // per thread: row stream g of the workgroup = row index r of the frame (in mirror-pair order), lane sl, k1
+    auto r_of = [&](int tid) { return 2 * unit + tid / L; };
+    auto row_of = [&](int tid) { return wide_k1_of_sub(r_of(tid)); };
+    auto partner = [&](int tid) {   // the partner cells, see mirror_of in upx_core.h
         const int g = tid / L, sl = tid % L;
-        const int gp = unit ? (g ^ 1) : g;
+        const int gp = (r_of(tid) >> 1) ? (g ^ 1) : g;
         return lds_all + gp * BUF + padp<P>((H + 1) * L - (row_of(tid) ? 1 : 0) - sl);
     };
-    auto load_row = [&](int tid, Thread& th, const cf* frame) {
-        const cf* data = frame + (size_t)row_of(tid) * N2 + tid % L;
+    auto gains = [&](int tid, Thread& th) {
+        // the gain rows of the own bins: issued early, their latency hides behind the row transform
+        const int lane = r_of(tid) * 8 * L + tid % L;
 #pragma unroll
-        for (int s = 0; s < P; ++s) th.x[s] = data[s * L];
-        S::template pass_compute<0>(th, tw, tid % L);
+        for (int s = 0; s < H; ++s) {
+            th.g0[s] = a.gain[lane + s * L];
+            th.g1[s] = a.n_gain > 1 ? a.gain[a.gain_stride + lane + s * L] : 0.f;
+        }
+        th.gn[0] = a.gain[N / 2];
+        th.gn[1] = a.n_gain > 1 ? a.gain[a.gain_stride + N / 2] : 0.f;
     };
     auto scatter0 = [&](int tid, Thread& th) { S::template pass_write<0>(th, lds_all + (tid / L) * BUF, tid % L); };
     auto mids = [&]() { S::template mid_passes<1>(ex, lds_all, tw); };
-    auto last_pass = [&](int tid, Thread& th) { S::template read_compute<LAST>(th, lds_all + (tid / L) * BUF, tw, tid % L); };
-    auto store_row = [&](int tid, Thread& th, cf* frame) {
-        cf* data = frame + (size_t)row_of(tid) * N2 + tid % L;
+    // (the whole-frame variant runs 16 waves per CU = 128 VGPRs: no eager LDS reads, gains and partners read at use)
+    auto last_pass = [&](int tid, Thread& th) { S::template read_compute<LAST, !WHOLE>(th, lds_all + (tid / L) * BUF, tw, tid % L); };
+    // forward row transforms up to the scatter of pass 0
+    auto forward_in = [&](int frame_in_chunk) {
+        if constexpr (WHOLE) {
+            ex.each([&](int tid, Thread& th) {   // step 1 in registers (tid = n2), transposed into the row buffers
+                // (addresses are rebuilt from laundered SGPR bases per phase: hoisted out of the frame loop they
+                //  would cost more registers than this 128-VGPR kernel has)
+                const int j = a.j0 + frame_in_chunk;
+                const bool exists = j >= a.j_lo && j < a.j_hi;
+                const long long n0 = (long long)j * a.hop;            // frame start (may be negative: halo frames)
+                const UPX_GLOBAL cf* in = opaque(a.in);
+                const UPX_GLOBAL float* w_a = opaque(a.w_a);
+                const UPX_GLOBAL cf* tw_n = opaque(a.tw_n);
 #pragma unroll
-        for (int s = 0; s < P; ++s) data[s * L] = th.x[s];
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const long long n = n0 + n1 * N2 + tid;
+                    th.x[n1] = mk(0.f, 0.f);
+                    if (exists && n >= 0 && n < a.t_in) th.x[n1] = scale(in[n], gat(w_a, (unsigned)tid, n1 * N2));
+                }
+                Dft<16>::run(th.x);
+                cf* b = lds_all + padp<P>(tid);
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1)
+                    b[wide_sub_of_k1(k1) * BUF] = k1 == 0 ? th.x[0] : cmul(th.x[k1], gat(tw_n, (unsigned)tid, k1 * N2));
+            });
+            ex.each2(
+                [&](int tid, Thread& th) { S::template read_compute<0, false>(th, lds_all + (tid / L) * BUF, tw, tid % L); },
+                scatter0);
+        } else {
+            const cf* zf = a.z + (size_t)frame_in_chunk * N;
+            ex.each2(
+                [&](int tid, Thread& th) {
+                    gains(tid, th);
+                    const cf* data = zf + (size_t)row_of(tid) * N2 + tid % L;
+#pragma unroll
+                    for (int s = 0; s < P; ++s) th.x[s] = data[s * L];
+                    S::template pass_compute<0>(th, tw, tid % L);
+                },
+                scatter0);
+        }
     };
-    // inverse row transform of what the mask / stage step left: own slots in registers, upper slots in LDS
+    // inverse row transform of what the mask / stage step left (own slots in registers, upper slots in LDS), then
+    // ROWS == 2: the rows go to the scratch (step 2 is a separate kernel); WHOLE: step 2 here, natural order out
     auto inverse_to = [&](cf* frame) {
         ex.each2(
             [&](int tid, Thread& th) {
@@ -291,29 +343,37 @@ UPX_HD void big_mid_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index)
             },
             scatter0);
         mids();
-        ex.each([&](int tid, Thread& th) {
-            last_pass(tid, th);
-            store_row(tid, th, frame);
-        });
+        if constexpr (WHOLE) {
+            ex.each2(last_pass, [&](int tid, Thread& th) {
+                cf* b = lds_all + (tid / L) * BUF + padp<P>(tid % L);
+#pragma unroll
+                for (int s = 0; s < P; ++s) b[s * SP] = th.x[s];
+            });
+            ex.each([&](int tid, Thread& th) {   // tid = n2: column of the sixteen rows, twiddle, radix-16 over k1
+                const cf* b = lds_all + padp<P>(tid);
+                const UPX_GLOBAL cf* tw_n = opaque(a.tw_n);
+                UPX_GLOBAL cf* out = opaque(frame);
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) {
+                    const cf v = lds_load(b + wide_sub_of_k1(k1) * BUF);
+                    th.x[k1] = k1 == 0 ? v : cmul(v, gat(tw_n, (unsigned)tid, k1 * N2));
+                }
+                Dft<16>::run(th.x);
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) gat(out, (unsigned)tid, n1 * N2) = th.x[n1];
+            });
+        } else {
+            ex.each([&](int tid, Thread& th) {
+                last_pass(tid, th);
+                cf* data = frame + (size_t)row_of(tid) * N2 + tid % L;
+#pragma unroll
+                for (int s = 0; s < P; ++s) data[s * L] = th.x[s];
+            });
+        }
     };
     const bool pair_ok = pp < a.ch / 2;   // (grid is exact; kept for safety with padded grids)
     for (int half = 0; half < 2 && pair_ok; ++half) {
-        cf* const zf = a.z + (size_t)(2 * pp + half) * N;
-        cf* const yf = a.y + (size_t)(2 * pp + half) * N;
-        ex.each2(
-            [&](int tid, Thread& th) {
-                // the gain rows of the own bins first: their latency hides behind the row transform
-                const int lane = (2 * unit + tid / L) * 8 * L + tid % L;
-#pragma unroll
-                for (int s = 0; s < H; ++s) {
-                    th.g0[s] = a.gain[lane + s * L];
-                    th.g1[s] = a.n_gain > 1 ? a.gain[a.gain_stride + lane + s * L] : 0.f;
-                }
-                th.gn[0] = a.gain[N / 2];
-                th.gn[1] = a.n_gain > 1 ? a.gain[a.gain_stride + N / 2] : 0.f;
-                load_row(tid, th, zf);
-            },
-            scatter0);
+        forward_in(2 * pp + half);
         mids();
         ex.each2(last_pass, [&](int tid, Thread& th) {
             cf* b = lds_all + (tid / L) * BUF + padp<P>(tid % L);
@@ -321,17 +381,17 @@ UPX_HD void big_mid_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index)
             for (int s = H; s < P; ++s) b[s * SP] = th.x[s];   // park the upper slots for the partners
         });
         ex.each([&](int tid, Thread& th) {
-            const bool first = unit == 0 && tid == 0;   // holds DC (slot 0) and Nyquist (slot H) of the frame
+            const bool first = r_of(tid) == 0 && tid % L == 0;   // holds DC (slot 0) and Nyquist (slot H) of the frame
             cf* const part = partner(tid);
             cf* const nyq = lds_all + H * SP;
-            const int lane = (2 * unit + tid / L) * 8 * L + tid % L;
+            const int lane = r_of(tid) * 8 * L + tid % L;
             cf nyq_y = mk(0.f, 0.f);
             float nyq_c = 0.f;
             if (first) {
                 const cf z = th.x[H];
                 cf cn = mk(0.f, 0.f), lsn = cn, rsn = cn;
                 for (int q = 0; q < a.n_gain; ++q) {
-                    const float g2 = q < 2 ? th.gn[q] : a.gain[q * a.gain_stride + N / 2];
+                    const float g2 = (q < 2 && !WHOLE) ? th.gn[q] : a.gain[q * a.gain_stride + N / 2];
                     if (g2 != 0.f) {
                         cf l = mk(g2 * (z.x + z.x), 0.f), r = mk(g2 * (z.y + z.y), 0.f), c, ls, rs;
                         mask_bin(l, r, c, ls, rs);
@@ -341,13 +401,26 @@ UPX_HD void big_mid_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index)
                 nyq_y = mk(lsn.x, rsn.x);
                 nyq_c = cn.x;
             }
-            cf zpart[H];
+            // WHOLE: the centre spectrum of the pair waits in the (still unused) yc frame of the pair instead of in
+            // registers, lane-private cells [slot][tid]: 32 VGPRs less across the inverse passes
+            UPX_GLOBAL cf* const cstage = opaque(a.yc + (size_t)pp * N);
+            cf ca_in[H];
+            if constexpr (WHOLE) {
+                if (half != 0) {
 #pragma unroll
-            for (int s = 0; s < H; ++s) zpart[s] = lds_load(part + (H - 1 - s) * SP);
+                    for (int s = 0; s < H; ++s) ca_in[s] = gat(cstage, (unsigned)tid, s * THREADS);
+                }
+            }
+            cf zpart[H];
+            if constexpr (!WHOLE) {
+#pragma unroll
+                for (int s = 0; s < H; ++s) zpart[s] = lds_load(part + (H - 1 - s) * SP);
+            }
 #pragma unroll
             for (int s = 0; s < H; ++s) {
                 const bool dc = s == 0 && first;
                 const cf za = th.x[s];
+                if constexpr (WHOLE) zpart[s] = lds_load(part + (H - 1 - s) * SP);
                 const cf zb = dc ? za : zpart[s];
                 const cf l0 = add_conj(za, zb), r0 = mi_sub_conj(za, zb);
                 cf c = mk(0.f, 0.f), ls = c, rs = c;
@@ -358,10 +431,14 @@ UPX_HD void big_mid_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index)
                         c = c + cq; ls = ls + lq; rs = rs + rq;
                     }
                 };
-                add_band(th.g0[s]);
-                if (a.n_gain > 1) {
-                    add_band(th.g1[s]);
-                    for (int q = 2; q < a.n_gain; ++q) add_band(a.gain[q * a.gain_stride + lane + s * L]);
+                if constexpr (WHOLE) {
+                    for (int q = 0; q < a.n_gain; ++q) add_band(gat(opaque(a.gain + q * a.gain_stride), (unsigned)lane, s * L));
+                } else {
+                    add_band(th.g0[s]);
+                    if (a.n_gain > 1) {
+                        add_band(th.g1[s]);
+                        for (int q = 2; q < a.n_gain; ++q) add_band(a.gain[q * a.gain_stride + lane + s * L]);
+                    }
                 }
                 th.x[s] = swap_add_i(ls, rs);
                 const cf ym = swap_conj_add_i(ls, rs);
@@ -373,33 +450,50 @@ UPX_HD void big_mid_program(Ex& ex, const BigArgs& a, cf* lds_all, int wg_index)
                 }
                 const cf cv = dc ? mk(c.x, nyq_c) : c;
                 if (half == 0) {
-                    th.cs[s] = cv;
+                    if constexpr (WHOLE) gat(cstage, (unsigned)tid, s * THREADS) = cv;
+                    else th.cs[s] = cv;
                 } else {
-                    const cf ca = th.cs[s], cb = cv;
+                    cf ca, cb = cv;
+                    if constexpr (WHOLE) ca = ca_in[s];
+                    else ca = th.cs[s];
                     cf ck = swap_add_i(ca, cb), cm = swap_conj_add_i(ca, cb);
                     if (dc) {
                         ck = mk(cb.x, ca.x);
                         cm = mk(cb.y, ca.y);
                     }
-                    th.cs[s] = ck;
-                    th.part[s] = cm;
+                    if constexpr (WHOLE) {
+                        gat(cstage, (unsigned)tid, s * THREADS) = ck;
+                        gat(cstage, (unsigned)tid, (H + s) * THREADS) = cm;
+                    } else {
+                        th.cs[s] = ck;
+                        th.part[s] = cm;
+                    }
                 }
             }
         });
-        inverse_to(yf);
+        inverse_to(a.y + (size_t)(2 * pp + half) * N);
     }
     if (pair_ok) {
         ex.each([&](int tid, Thread& th) {
-            const bool first = unit == 0 && tid == 0;
+            const bool first = r_of(tid) == 0 && tid % L == 0;
             cf* const part = partner(tid);
+            const UPX_GLOBAL cf* const cstage = opaque(a.yc + (size_t)pp * N);
 #pragma unroll
             for (int s = 0; s < H; ++s) {
-                th.x[s] = th.cs[s];
+                cf own, mir;
+                if constexpr (WHOLE) {
+                    own = gat(cstage, (unsigned)tid, s * THREADS);
+                    mir = gat(cstage, (unsigned)tid, (H + s) * THREADS);
+                } else {
+                    own = th.cs[s];
+                    mir = th.part[s];
+                }
+                th.x[s] = own;
                 if (s == 0) {
                     cf* dst = first ? lds_all + H * SP : part + (H - 1) * SP;
-                    *dst = th.part[0];
+                    *dst = mir;
                 } else {
-                    part[(H - 1 - s) * SP] = th.part[s];
+                    part[(H - 1 - s) * SP] = mir;
                 }
             }
         });

@@ -214,13 +214,14 @@ __global__ __launch_bounds__(B::Row::WG) void upx_big_frame_kernel(upx::BigArgs 
     DevExec<B::Row::WAVE_SYNC, B::Row::P> ex;
     upx::big_frame_program<B>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
-// rows -> mask -> rows of one frame pair and one mirror pair of rows (N1 == 16); two row streams per workgroup
-template <class B>
-__global__ __launch_bounds__(2 * B::Row::LANES) void upx_big_mid_kernel(upx::BigArgs a) {
+// rows -> mask -> rows (N1 == 16) of one frame pair: ROWS = 2, one mirror pair of rows per workgroup (two row
+// streams); ROWS = 16 (N = 16 384), the whole frame per workgroup with steps 1 and 2 in registers
+template <class B, int ROWS>
+__global__ __launch_bounds__(ROWS * B::Row::LANES) void upx_big_mid_kernel(upx::BigArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if constexpr (B::N1 == 16) {
+    if constexpr (B::N1 == 16 && (ROWS == 2 || ROWS * B::Row::LANES == B::N2)) {
         DevExec<false, B::Row::P> ex;
-        upx::big_mid_program<B>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+        upx::big_mid_program<B, ROWS>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
     }
 }
 template <class B>
@@ -261,7 +262,9 @@ template <class B>
 struct BigImpl {
     using Row = typename B::Row;
     static constexpr int kRowLds = Row::LDS_CF * (int)sizeof(upx::cf);
-    static constexpr int kMidLds = (2 * Row::PITCH + Row::TW_CF) * (int)sizeof(upx::cf);
+    // N = 16 384: the sixteen 1024-point rows of a frame fit one workgroup's LDS (149 KB): whole-frame variant
+    static constexpr int kMidRows = (B::N1 == 16 && 16 * Row::LANES == B::N2 && (16 * Row::PITCH + Row::TW_CF) * 8 <= 160 * 1024) ? 16 : 2;
+    static constexpr int kMidLds = (kMidRows * Row::PITCH + Row::TW_CF) * (int)sizeof(upx::cf);
     static unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
     static unsigned row_wgs(int rows) { return (unsigned)((rows + Row::G - 1) / Row::G); }
     static void rows(upx::cf* buf, const upx::cf* tw, int n_rows, hipStream_t st) {
@@ -272,16 +275,19 @@ struct BigImpl {
         const int ch = a.ch;
         // y (ch frames) and yc (ch/2 frames) are adjacent in the scratch: one launch covers both
         const int inv_frames = ch + ch / 2;
-        if (B::N1 == 16) {
+        if (B::N1 == 16 && kMidRows == 16) {
+            // whole frame per workgroup: audio in, time-domain y / yc out
+            hipLaunchKernelGGL((upx_big_mid_kernel<B, kMidRows>), dim3((unsigned)(ch / 2)), dim3(kMidRows * Row::LANES), kMidLds, st, a);
+        } else if (B::N1 == 16) {
             hipLaunchKernelGGL(upx_big_step1_audio_kernel<B>, dim3(blocks((long long)ch * B::N2)), dim3(256), 0, st, a);
             // row transforms, mask and inverse row transforms fused: one workgroup per (frame pair, mirror pair of rows)
-            hipLaunchKernelGGL(upx_big_mid_kernel<B>, dim3((unsigned)(ch / 2) * 8), dim3(2 * Row::LANES), kMidLds, st, a);
+            hipLaunchKernelGGL((upx_big_mid_kernel<B, kMidRows>), dim3((unsigned)(ch / 2) * 8), dim3(kMidRows * Row::LANES), kMidLds, st, a);
         } else {
             hipLaunchKernelGGL(upx_big_frame_kernel<B>, dim3(row_wgs(ch)), dim3(Row::WG), kRowLds, st, a);
             hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks(upx::big_mask_threads<B>(ch / 2))), dim3(256), 0, st, a);
             rows(a.y, a.tw_rows, inv_frames * B::N1, st);
         }
-        if (B::N1 == 16)
+        if (B::N1 == 16 && kMidRows == 2)
             hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)inv_frames * B::N2)), dim3(256), 0, st, a.y, a.tw_n, inv_frames);
         hipLaunchKernelGGL(upx_big_ola_kernel<B>, dim3(blocks((long long)(a.m1 - a.m0) * a.hop)), dim3(256), 0, st, a);
     }
@@ -292,7 +298,7 @@ struct BigImpl {
             e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_frame_kernel<B>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kRowLds);
         if (!e && B::N1 == 16)
-            e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_mid_kernel<B>),
+            e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_big_mid_kernel<B, kMidRows>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kMidLds);
         return e;
     }
