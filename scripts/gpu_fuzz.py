@@ -1,0 +1,54 @@
+"""One-off wider randomised sweep on the GPU (not part of the test suite): many random plans, incl. same-size
+neighbours (merged launches), streaming with small chunks, and overlaps that route to every kernel path."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import upmix_amd as ux
+from oracle import upmix_oracle as orc
+
+def rms(a): return float(np.sqrt(np.mean(np.square(a)))) if a.size else 0.0
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+sizes = [64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
+overlaps = [0.5, 0.75, 0.875, 0.6, 0.7, 0.9, 0.75, 0.75]
+windows = sorted(ux.WINDOW_FUNCS)
+worst = 0.0
+t0 = time.time()
+for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
+    n_bands = int(rng.integers(1, 6))
+    edges = np.sort(rng.uniform(10.0, 20000.0, size=n_bands + 1))
+    overlap = overlaps[int(rng.integers(len(overlaps)))]
+    wname = windows[int(rng.integers(len(windows)))]
+    mode = ["raised_cosine", "hard_zero"][int(rng.integers(2))]
+    total = int(rng.integers(1, 300000))
+    gb, ob, prev = [], [], 0.0
+    n_prev = None
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        n = n_prev if (n_prev and rng.random() < 0.5) else sizes[int(rng.integers(len(sizes)))]   # repeats -> merged launches
+        n_prev = n
+        if int(n * (1 - overlap)) < 1 or -(-n // int(n * (1 - overlap))) > 64:
+            continue
+        width = 0.25 * hi
+        gb.append(ux.MultiBandExtractorAccu(n, overlap, ux.WINDOW_FUNCS[wname], lo, hi, 44100, mode, prev, width))
+        ob.append(orc.Band(n, overlap, lo, hi, 44100, mode, prev, width, window=orc.WINDOWS[wname]))
+        prev = width
+    if not gb:
+        continue
+    x = orc.synthetic_stereo(total, (11, trial))
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+    got = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 44100, gb)
+    errs = [rms(g.astype(np.float64) - r) for g, r in zip(got, ref)]
+    plan = ux.DevicePlan(gb)
+    try:
+        chunk = int(rng.integers(1, max(2, total)))
+        try:
+            gc = plan.process_chunked(x, chunk)
+            errs += [rms(g.astype(np.float64) - r) for g, r in zip(gc, ref)]
+        except NotImplementedError:
+            pass   # hops that do not share a shard grid
+    finally:
+        plan.close()
+    bad = any((not np.all(np.isfinite(g))) for g in got)
+    worst = max(worst, max(errs))
+    flag = "BAD" if (bad or max(errs) > 1e-5) else "ok"
+    print(f"{trial:3d} {flag} N={[b.block_size for b in gb]} ov={overlap} {wname} {mode} T={total} err={max(errs):.2e}", flush=True)
+print("worst", worst, "elapsed", time.time() - t0)
