@@ -93,6 +93,17 @@ int upx_process(upx_plan* plan, const float* stereo, int64_t n_samples, float* o
 int upx_process_chunked(upx_plan* plan, const float* stereo, int64_t n_samples, float* out_c, float* out_l,
                         float* out_r, int64_t chunk);
 
+/*
+ * A batch of independent tracks through ONE plan (BASELINE configs[4]; the reference's analogue is running
+ * main.py:36-80 once per file): track t is stereo[t] ([n_samples[t]][2] float32) -> out_c[t] / out_l[t] / out_r[t]
+ * (float32 [n_samples[t]]).  The tracks (cut into chunks exactly as upx_process cuts a long signal) form one queue
+ * of work items; the upload of item i+1, the kernels of item i and the download of item i-1 overlap across track
+ * boundaries.  Each track's result is bit-identical to a upx_process call on that track alone.  Zero-length tracks
+ * are skipped.
+ */
+int upx_process_tracks(upx_plan* plan, int32_t n_tracks, const float* const* stereo, const int64_t* n_samples,
+                       float* const* out_c, float* const* out_l, float* const* out_r);
+
 /* ---- device-resident interface (benchmarks, sharding, pipelines) -------- */
 int upx_dev_alloc(upx_plan* plan, void** ptr, size_t bytes);
 int upx_dev_free(upx_plan* plan, void* ptr);

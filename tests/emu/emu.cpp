@@ -12,6 +12,10 @@
 
 #include "../../upmix_amd/csrc/upx_core.h"
 #include "../../upmix_amd/csrc/upx_big.h"
+#include "../../upmix_amd/csrc/upx_pipeline.h"
+
+#include <atomic>
+#include <chrono>
 
 namespace {
 template <int PTS>
@@ -210,4 +214,37 @@ extern "C" int emu_big_band(int log2n, int hop, const float* in, long long t_in,
     UPX_BIG(6) UPX_BIG(7) UPX_BIG(8) UPX_BIG(9) UPX_BIG(10) UPX_BIG(11) UPX_BIG(12) UPX_BIG(13) UPX_BIG(14) UPX_BIG(15) UPX_BIG(16)
 #undef UPX_BIG
     return -1;
+}
+
+// ---- hand-over logic of the streamed host calls (upx_pipeline.h) with injected failures ----------
+// submit / complete sleep `*_us` microseconds; item `fail_submit` / `fail_complete` (-1: none) returns -3.
+// Reports how many items each side finished.  A regression of the round-1 hang shows up as a test timeout.
+extern "C" int emu_pipeline(long long n_items, long long fail_submit, long long fail_complete, int submit_us,
+                            int complete_us, long long* n_submitted, long long* n_completed, char* msg, int msg_len) {
+    std::atomic<long long> subs{0}, comps{0};
+    std::atomic<bool> order_ok{true};
+    auto submit = [&](int64_t i, std::string& m) -> int {
+        // buffer set i % 2 is free: item i-2 is complete
+        if (i >= 2 && comps.load() < i - 1) order_ok = false;
+        std::this_thread::sleep_for(std::chrono::microseconds(submit_us));
+        if (i == fail_submit) { m = "injected submit failure"; return -3; }
+        subs = i + 1;
+        return 0;
+    };
+    auto complete = [&](int64_t i, std::string& m) -> int {
+        if (subs.load() < i + 1) order_ok = false;   // never complete what has not been submitted
+        std::this_thread::sleep_for(std::chrono::microseconds(complete_us));
+        if (i == fail_complete) { m = "injected download failure"; return -3; }
+        comps = i + 1;
+        return 0;
+    };
+    std::string err;
+    const int rc = upx::run_pipeline((int64_t)n_items, submit, complete, err);
+    *n_submitted = subs;
+    *n_completed = comps;
+    if (msg && msg_len > 0) {
+        std::strncpy(msg, err.c_str(), (size_t)msg_len - 1);
+        msg[msg_len - 1] = 0;
+    }
+    return order_ok ? rc : -100;
 }

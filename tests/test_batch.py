@@ -1,0 +1,180 @@
+"""
+Batch of independent tracks (BASELINE configs[4]; SURVEY.md 8(e): replicas only, no collective).
+CPU: the track assignment and the per-rank driver with the ORACLE as engine, world_size 2 over gloo.
+GPU (-m gpu): upx_process_tracks through the C ABI against per-track calls (bit for bit) and the oracle.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import rms
+from oracle import upmix_oracle as orc
+from upmix_amd import batch
+
+LENGTHS = [9000, 300, 12345, 1, 4096, 7777, 20011, 513, 2048]   # ragged; several shorter than the largest STFT
+
+
+def make_tracks(lengths=LENGTHS, seed=4):
+    return [orc.synthetic_stereo(n, (seed, t)) for t, n in enumerate(lengths)]
+
+
+def oracle_engine(bands):
+    def run(xs):
+        return [orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), bands) for x in xs]
+    return run
+
+
+def test_assignment_is_a_partition():
+    for n in (0, 1, 7, 64):
+        for world in (1, 2, 3, 8):
+            parts = [batch.assign_tracks(n, r, world) for r in range(world)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert batch.assign_tracks(64, 3, 8) == list(range(3, 64, 8))   # 8 tracks per GPU (configs[4])
+    with pytest.raises(ValueError):
+        batch.assign_tracks(4, 2, 2)
+
+
+def test_rank_driver_in_process():
+    bands = orc.plan_bands([0, 300, 3000], 0.75, orc.win_blackman_harris, 48000, max_block_size=1024)
+    tracks = make_tracks()
+    merged = {}
+    for rank in range(3):
+        # a rank only needs the tracks it owns
+        mine = batch.assign_tracks(len(tracks), rank, 3)
+        sparse = [t if i in mine else None for i, t in enumerate(tracks)]
+        merged.update(batch.process_tracks_rank(sparse, bands, rank, 3, engine=oracle_engine(bands)))
+    assert sorted(merged) == list(range(len(tracks)))
+    for i, x in enumerate(tracks):
+        ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), bands)
+        for g, r in zip(merged[i], ref):
+            assert g.shape == (len(x),) and np.array_equal(g, r)
+
+
+def _worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous only: the data path has no collective
+    bands = orc.plan_bands([0, 300, 3000], 0.75, orc.win_blackman_harris, 48000, max_block_size=1024)
+    tracks = make_tracks()
+    res = batch.process_tracks_rank(tracks, bands, rank, world, engine=oracle_engine(bands))
+    np.savez(os.path.join(tmp, f"rank{rank}.npz"), idx=np.array(sorted(res)),
+             **{f"{k}{i}": v for i, planes in res.items() for k, v in zip("clr", planes)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_replicas(tmp_path):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 2
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    bands = orc.plan_bands([0, 300, 3000], 0.75, orc.win_blackman_harris, 48000, max_block_size=1024)
+    tracks = make_tracks()
+    seen = []
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"rank{rank}.npz"))
+        assert list(z["idx"]) == batch.assign_tracks(len(tracks), rank, world)
+        for i in z["idx"]:
+            x = tracks[int(i)]
+            ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), bands)
+            for k, r in zip("clr", ref):
+                assert np.array_equal(z[f"{k}{int(i)}"], r)
+            seen.append(int(i))
+    assert sorted(seen) == list(range(len(tracks)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_process_tracks_equals_per_track_calls_and_oracle(monkeypatch):
+    import upmix_amd as ux
+    # a small streaming chunk so that the long tracks are cut into several work items (as 5-min tracks are at 2^22)
+    monkeypatch.setenv("UPX_STREAM_CHUNK", "16384")
+    edges = [0, 30, 120, 480, 1920, 7680]
+    bands = ux.chain_bands(edges, 0.75, ux.make_blackman_harris, 48000, max_block_size=8192, verbose=False)
+    ref_bands = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, 48000, max_block_size=8192)
+    lengths = [60000, 300, 100001, 1, 8192, 131072 + 77, 5000, 45000, 0, 2047]   # one empty, several < N = 8192
+    tracks = make_tracks(lengths)
+    got = ux.process_tracks(tracks, bands)
+    assert len(got) == len(tracks)
+    for x, planes in zip(tracks, got):
+        alone = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, bands)
+        ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ref_bands)
+        for g, a, r in zip(planes, alone, ref):
+            assert g.dtype == np.float32 and g.shape == (len(x),)
+            assert np.array_equal(g, a)                                   # bit for bit the per-track call
+            if len(x):
+                assert rms(g.astype(np.float64) - r) <= 1e-5              # BASELINE tolerance vs the oracle
+    # float64 / non-contiguous inputs are accepted like the reference accepts any real array
+    odd = [np.asfortranarray(t.astype(np.float64)) for t in tracks[:3]]
+    for planes, again in zip(got[:3], ux.process_tracks(odd, bands)):
+        for g, a in zip(planes, again):
+            assert np.array_equal(g, a)
+    with pytest.raises(ValueError):
+        ux.process_tracks([np.zeros((10, 3), np.float32)], bands)
+
+
+@pytest.mark.gpu
+def test_rank_driver_on_gpu_and_failed_download_returns(monkeypatch):
+    import upmix_amd as ux
+    from upmix_amd import _lib
+    monkeypatch.setenv("UPX_STREAM_CHUNK", "16384")
+    bands = ux.chain_bands([0, 300, 3000], 0.75, ux.make_blackman_harris, 48000, max_block_size=4096,
+                           threshold_factor=64, verbose=False)
+    tracks = make_tracks([40000, 70000, 500, 90000])
+    whole = ux.process_tracks(tracks, bands)
+    res = {}
+    for rank in range(2):
+        res.update(batch.process_tracks_rank(tracks, bands, rank, 2, device=0))
+    for i, planes in enumerate(whole):
+        for g, a in zip(res[i], planes):
+            assert np.array_equal(g, a)
+    # a failing download with work items left must surface as an error, not hang the call
+    monkeypatch.setenv("UPX_TEST_FAIL_DOWNLOAD", "1")
+    with pytest.raises(_lib.UpmixHipError, match="download of a work item failed"):
+        ux.process_tracks(tracks, bands)
+    monkeypatch.delenv("UPX_TEST_FAIL_DOWNLOAD")
+    again = ux.process_tracks(tracks, bands)      # the plan is usable afterwards
+    for planes, ref in zip(again, whole):
+        for g, a in zip(planes, ref):
+            assert np.array_equal(g, a)
+
+
+@pytest.mark.gpu
+def test_entry_point_from_several_threads():
+    """The reference's caller is a ThreadPoolExecutor (center_extraction.py:499-501): the drop-in entry must be
+    callable from several threads at once, with different band plans and with the same one."""
+    from concurrent.futures import ThreadPoolExecutor
+    import upmix_amd as ux
+    plans = [ux.chain_bands([0, 300, 3000], 0.75, ux.make_blackman_harris, 48000, max_block_size=4096,
+                            threshold_factor=64, verbose=False),
+             ux.chain_bands([0, 1000], 0.5, ux.make_hann, 44100, max_block_size=2048, verbose=False),
+             ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 48000, max_block_size=8192,
+                            verbose=False)]
+    xs = [orc.synthetic_stereo(30000 + 1111 * i, 50 + i) for i in range(3)]
+    serial = [ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, p) for x, p in zip(xs, plans)]
+    jobs = [(i % 3) for i in range(18)]          # every plan from several threads at the same time
+
+    def work(i):
+        x = xs[i]
+        return i, ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, plans[i])
+
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        for i, planes in pool.map(work, jobs):
+            for g, a in zip(planes, serial[i]):
+                assert np.array_equal(g, a)
+    # more distinct plans than the cache holds, concurrently: nothing in use is evicted
+    many = [ux.chain_bands([0, 200.0 + 50 * k], 0.75, ux.make_hann, 48000, max_block_size=1024, verbose=False)
+            for k in range(7)]
+    x = xs[0]
+    ref = [ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, p) for p in many]
+    with ThreadPoolExecutor(max_workers=7) as pool:
+        outs = list(pool.map(lambda p: ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, p), many))
+    for a, b in zip(outs, ref):
+        for g, h in zip(a, b):
+            assert np.array_equal(g, h)

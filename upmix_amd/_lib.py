@@ -40,6 +40,7 @@ SIGNATURES = {
     "upx_plan_set_blocks_per_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "upx_process": (C.c_int, [C.c_void_p, f32p, C.c_int64, f32p, f32p, f32p]),
     "upx_process_chunked": (C.c_int, [C.c_void_p, f32p, C.c_int64, f32p, f32p, f32p, C.c_int64]),
+    "upx_process_tracks": (C.c_int, [C.c_void_p, C.c_int32, vpp, C.POINTER(C.c_int64), vpp, vpp, vpp]),
     "upx_dev_alloc": (C.c_int, [C.c_void_p, vpp, C.c_size_t]),
     "upx_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "upx_dev_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),

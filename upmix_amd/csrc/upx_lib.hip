@@ -21,6 +21,7 @@
 #include "../../include/upmix_hip.h"
 #include "upx_core.h"
 #include "upx_big.h"
+#include "upx_pipeline.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -41,7 +42,9 @@ int fail(int code, const char* fmt, ...) {
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(UPX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? UPX_ERR_NOMEM : UPX_ERR_HIP, "%s: %s", #expr,   \
+                        hipGetErrorString(e_));                                                    \
     } while (0)
 
 // ---------------------------------------------------------------------------
@@ -127,13 +130,19 @@ __global__ void upx_scale_kernel(float* x, long long n, float s) {
 }
 
 // ---- device-side WAV codec + export layouts (main.py:43-55, 85-97, 110-157) -------------------
-__device__ __forceinline__ float upx_decode_sample(const unsigned char* p, long long i, int fmt) {
-    if (fmt == UPX_PCM16) return (float)reinterpret_cast<const short*>(p)[i] * (1.0f / 32768.0f);
-    if (fmt == UPX_PCM32) return (float)((double)reinterpret_cast<const int*>(p)[i] * (1.0 / 2147483648.0));
-    if (fmt == UPX_F32) return reinterpret_cast<const float*>(p)[i];
+// what soundfile.read returns for sample i (float64, int / 2^(bits-1))
+__device__ __forceinline__ double upx_decode_sample_f64(const unsigned char* p, long long i, int fmt) {
+    if (fmt == UPX_PCM16) return (double)reinterpret_cast<const short*>(p)[i] * (1.0 / 32768.0);
+    if (fmt == UPX_PCM32) return (double)reinterpret_cast<const int*>(p)[i] * (1.0 / 2147483648.0);
+    if (fmt == UPX_F32) return (double)reinterpret_cast<const float*>(p)[i];
     const unsigned char* b = p + 3 * i;   // 24-bit little endian, sign extended
     int v = (int)b[0] | ((int)b[1] << 8) | ((int)(signed char)b[2] << 16);
-    return (float)v * (1.0f / 8388608.0f);
+    return (double)v * (1.0 / 8388608.0);
+}
+// the float32 signal the kernels transform (center_extraction.py hands float64 to a float64 FFT; here the
+// cast happens once, at decode)
+__device__ __forceinline__ float upx_decode_sample(const unsigned char* p, long long i, int fmt) {
+    return (float)upx_decode_sample_f64(p, i, fmt);
 }
 __global__ void upx_decode_kernel(const unsigned char* pcm, int fmt, int channels, long long n, float* stereo) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -143,11 +152,13 @@ __global__ void upx_decode_kernel(const unsigned char* pcm, int fmt, int channel
         stereo[2 * i + 1] = r;
     }
 }
-__device__ __forceinline__ void upx_encode_sample(unsigned char* p, long long i, int fmt, float x) {
-    if (fmt == UPX_F32) { reinterpret_cast<float*>(p)[i] = x; return; }
+// x is a double because main.py hands float64 arrays to the writer whenever one column is float64 (AB: L + R of
+// the decoded file, main.py:112-114); float32 columns arrive here exactly (float -> double is lossless)
+__device__ __forceinline__ void upx_encode_sample(unsigned char* p, long long i, int fmt, double x) {
+    if (fmt == UPX_F32) { reinterpret_cast<float*>(p)[i] = (float)x; return; }
     const int bits = fmt;
     const double full = (double)((1ll << (bits - 1)) - 1);
-    double q = rint((double)x * full);
+    double q = rint(x * full);
     q = q > full ? full : (q < -full - 1.0 ? -full - 1.0 : q);
     const long long v = (long long)q;
     if (fmt == UPX_PCM16) reinterpret_cast<short*>(p)[i] = (short)v;
@@ -156,8 +167,9 @@ __device__ __forceinline__ void upx_encode_sample(unsigned char* p, long long i,
 }
 // planes are scaled like `final_x *= scale_factor` (float32 array times a float64 scalar: product in double,
 // rounded to float32), then combined in float32 exactly as main.py does
-__global__ void upx_export_kernel(const float* c, const float* l, const float* r, const float* stereo, long long n,
-                                  double scale, int mode, int fmt, unsigned char* o0, unsigned char* o1, unsigned char* o2) {
+__global__ void upx_export_kernel(const float* c, const float* l, const float* r, const unsigned char* pcm, int in_fmt,
+                                  int channels, long long n, double scale, int mode, int fmt, unsigned char* o0,
+                                  unsigned char* o1, unsigned char* o2) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float fc = (float)((double)c[i] * scale), fl = (float)((double)l[i] * scale), fr = (float)((double)r[i] * scale);
         if (mode == UPX_EXPORT_STEREO_SUM) {
@@ -168,8 +180,11 @@ __global__ void upx_export_kernel(const float* c, const float* l, const float* r
             upx_encode_sample(o1, 2 * i, fmt, fc); upx_encode_sample(o1, 2 * i + 1, fmt, fc);
             upx_encode_sample(o2, 2 * i, fmt, 0.f); upx_encode_sample(o2, 2 * i + 1, fmt, fr);
         } else {
+            // main.py:112-113: upmix_sum in float32, orig_sum = L + R in float64 (the decoded file)
             upx_encode_sample(o0, 2 * i, fmt, (fl + fc) + fr);
-            upx_encode_sample(o0, 2 * i + 1, fmt, stereo[2 * i] + stereo[2 * i + 1]);
+            const double dl = upx_decode_sample_f64(pcm, channels == 2 ? 2 * i : i, in_fmt);
+            const double dr = channels == 2 ? upx_decode_sample_f64(pcm, 2 * i + 1, in_fmt) : dl;
+            upx_encode_sample(o0, 2 * i + 1, fmt, dl + dr);
         }
     }
 }
@@ -482,6 +497,15 @@ int load_rccl() {
         if (r_ != ncclSuccess) return fail(UPX_ERR_RCCL, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
     } while (0)
 
+// streams the automatic launch geometry of a fused band aims for: every resident workgroup slot of the chip once
+long long max_auto_streams(const upx_plan* p, const BandState& s) {
+    int resident = (s.kern->wpe * 256) / s.kern->wg;              // workgroups per CU by registers
+    const int by_lds = (160 * 1024) / s.kern->lds_bytes;          // ... and by LDS
+    if (resident > by_lds) resident = by_lds;
+    if (resident < 1) resident = 1;
+    return (long long)p->n_cu * resident * s.kern->g;
+}
+
 int grid_for(long long n) {
     long long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -532,7 +556,12 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(UPX_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n_dev) return fail(UPX_ERR_INVALID, "device %d out of range (0..%d)", device, n_dev - 1);
     HIP_TRY(hipSetDevice(device));
-    upx_plan* p = new upx_plan();
+    // every early return below releases what has been created so far (stream, events, device memory)
+    struct Guard {
+        upx_plan* p;
+        ~Guard() { if (p) upx_plan_destroy(p); }
+    } guard{new upx_plan()};
+    upx_plan* p = guard.p;
     p->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -551,10 +580,8 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         // fused streaming kernel when the hop is N/2, N/4 or N/8 and N <= 8192; otherwise the unfused path
         s.kern = (s.n % s.hop == 0 && !std::getenv("UPX_FORCE_UNFUSED")) ? find_kernel(s.log2n, s.n / s.hop, default_variant()) : nullptr;
         if (!s.kern) s.big = find_big(s.log2n);
-        if (int e = s.kern ? s.kern->prepare() : s.big->prepare()) {
-            upx_plan_destroy(p);
+        if (int e = s.kern ? s.kern->prepare() : s.big->prepare())
             return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
-        }
         const int nb = s.n / 2 + 1;
         // Merge with the previous band when it has the same STFT size, hop and (bit-identical) windows:
         // the transforms are then the same linear operators and only gain -> mask runs per band.
@@ -646,6 +673,15 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         HIP_TRY(hipMemcpy(s.d_gain, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (p->scratch_cf) HIP_TRY(hipMalloc(&p->d_scratch, p->scratch_cf * sizeof(upx::cf)));
+    // stream seam buffer of the fused kernels, sized for the largest automatic launch (no allocation, and no
+    // stream synchronisation, inside upx_process_device unless upx_plan_set_blocks_per_stream asks for more streams)
+    for (const auto& s : p->bands) {
+        if (!s.kern || s.group_size == 0) continue;
+        const size_t need = (size_t)(max_auto_streams(p, s) + s.kern->g) * 3 * (size_t)(s.k - 1) * s.hop;
+        if (need > p->seam_floats) p->seam_floats = need;
+    }
+    if (p->seam_floats) HIP_TRY(hipMalloc(&p->d_seam, p->seam_floats * sizeof(float)));
+    guard.p = nullptr;
     *out = p;
     return UPX_OK;
 }
@@ -786,11 +822,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         }
         // blocks per stream: fill every resident workgroup slot once; even (whole frame pairs), at least 8 and at
         // least K (a stream's tail must end inside the next stream).  Streams cover frames m_lo-1 .. m_hi-1.
-        int resident = (s.kern->wpe * 256) / s.kern->wg;              // workgroups per CU by registers
-        const int by_lds = (160 * 1024) / s.kern->lds_bytes;              // ... and by LDS
-        if (resident > by_lds) resident = by_lds;
-        if (resident < 1) resident = 1;
-        long long target_streams = (long long)p->n_cu * resident * s.kern->g;
+        const long long target_streams = max_auto_streams(p, s);
         long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + 1 + target_streams - 1) / target_streams;
         if (s.blocks_override <= 0 && f < 8) f = 8;
         if (f < s.k) f = s.k;
@@ -850,19 +882,63 @@ static bool shard_geometry(const upx_plan* p, int64_t* grid, int64_t* spill) {
     return true;
 }
 
-int upx_process_chunked(upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r,
-                        int64_t chunk) {
-    if (!p || n < 0 || chunk < 1) return fail(UPX_ERR_INVALID, "upx_process_chunked: bad argument");
+namespace {
+// One work item of a streamed host call: a chunk of a track (or a whole short track).
+struct PipeItem {
+    const float* src = nullptr;          // host stereo, first sample of the item
+    int64_t t_in = 0, own = 0, t_out = 0;   // samples uploaded, samples whose frames are owned, output plane length
+    float* dst[3] = {nullptr, nullptr, nullptr};   // host planes at the item's first owned sample
+    int64_t seam = 0;                    // > 0: add this many spill samples of the previous item (same track) ...
+    int64_t prev_own = 0;                // ... found at this offset of the previous item's planes
+};
+
+// Cuts one track into items exactly as upx_process does on its own (so a batch equals per-track calls bit for
+// bit): chunks of `chunk` owned samples on the shard grid when the track is long enough, else one item.
+int items_of_track(const upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r,
+                   int64_t chunk, bool force_chunks, std::vector<PipeItem>& items) {
     if (n == 0) return UPX_OK;
-    if (!stereo || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process_chunked: NULL buffer");
     int64_t grid = 0, spill = 0;
-    if (!shard_geometry(p, &grid, &spill))
-        return fail(UPX_ERR_UNSUPPORTED, "the bands' hops do not share a shard grid: the signal cannot be cut into chunks");
+    const bool gridded = shard_geometry(p, &grid, &spill);
+    bool cut = chunk > 0 && gridded && (force_chunks || (n >= 2 * chunk && chunk >= 4 * spill));
+    if (!cut && n >= (1LL << 29)) {
+        if (!gridded) return fail(UPX_ERR_INVALID, "signals of 2^29 samples or more need hops that share a shard grid");
+        chunk = 1LL << 26;
+        cut = true;
+    }
+    if (!cut) {
+        PipeItem it;
+        it.src = stereo; it.t_in = n; it.own = n; it.t_out = n;
+        it.dst[0] = out_c; it.dst[1] = out_l; it.dst[2] = out_r;
+        items.push_back(it);
+        return UPX_OK;
+    }
     // owned samples per chunk: a multiple of the grid, at least the spill (a seam then ends inside the next chunk)
     int64_t own = (chunk + grid - 1) / grid * grid;
     if (own < spill) own = (spill + grid - 1) / grid * grid;
     if (own + spill >= (1LL << 29)) return fail(UPX_ERR_INVALID, "chunk too long (2^29 samples per launch)");
     const int64_t n_chunks = (n + own - 1) / own;
+    for (int64_t i = 0; i < n_chunks; ++i) {
+        const int64_t start = i * own;
+        const bool last = i == n_chunks - 1;
+        PipeItem it;
+        it.src = stereo + 2 * start;
+        it.own = last ? n - start : own;
+        it.t_in = n - start < it.own + spill ? n - start : it.own + spill;
+        it.t_out = last ? it.own : it.own + spill;
+        it.dst[0] = out_c + start; it.dst[1] = out_l + start; it.dst[2] = out_r + start;
+        if (i > 0) {
+            it.seam = spill < it.t_out ? spill : it.t_out;
+            it.prev_own = own;
+        }
+        items.push_back(it);
+    }
+    return UPX_OK;
+}
+
+// Runs the items through the device: the upload of item i+1, the kernels of item i and the download of item i-1
+// overlap (two copy streams + the completer thread of upx::run_pipeline).
+int run_items(upx_plan* p, const std::vector<PipeItem>& items) {
+    if (items.empty()) return UPX_OK;
     HIP_TRY(hipSetDevice(p->device));
     if (!p->s_h2d) {
         HIP_TRY(hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
@@ -872,7 +948,12 @@ int upx_process_chunked(upx_plan* p, const float* stereo, int64_t n, float* out_
             HIP_TRY(hipEventCreateWithFlags(&p->ev_comp[i], hipEventDisableTiming));
         }
     }
-    const size_t in_floats = (size_t)(own + spill) * 2, out_floats = (size_t)(own + spill) * 3;
+    int64_t cap_in = 0, cap_out = 0;
+    for (const auto& it : items) {
+        if (it.t_in > cap_in) cap_in = it.t_in;
+        if (it.t_out > cap_out) cap_out = it.t_out;
+    }
+    const size_t in_floats = (size_t)cap_in * 2, out_floats = (size_t)cap_out * 3;
     if (in_floats > p->pipe_in_floats || out_floats > p->pipe_out_floats) {
         HIP_TRY(hipDeviceSynchronize());
         for (int i = 0; i < 2; ++i) {
@@ -881,158 +962,115 @@ int upx_process_chunked(upx_plan* p, const float* stereo, int64_t n, float* out_
             p->d_pipe_in[i] = p->d_pipe_out[i] = nullptr;
         }
         p->pipe_in_floats = p->pipe_out_floats = 0;
+        const size_t want_in = in_floats > p->pipe_in_floats ? in_floats : p->pipe_in_floats;
         for (int i = 0; i < 2; ++i) {
-            hipError_t e = hipMalloc(&p->d_pipe_in[i], in_floats * sizeof(float));
+            hipError_t e = hipMalloc(&p->d_pipe_in[i], want_in * sizeof(float));
             if (e == hipSuccess) e = hipMalloc(&p->d_pipe_out[i], out_floats * sizeof(float));
-            if (e != hipSuccess) return fail(UPX_ERR_NOMEM, "hipMalloc for a %lld-sample chunk: %s", (long long)own, hipGetErrorString(e));
+            if (e != hipSuccess) return fail(UPX_ERR_NOMEM, "hipMalloc for a %lld-sample work item: %s", (long long)cap_out, hipGetErrorString(e));
         }
-        p->pipe_in_floats = in_floats;
+        p->pipe_in_floats = want_in;
         p->pipe_out_floats = out_floats;
     }
-    const size_t plane = (size_t)(own + spill);
+    const size_t plane = p->pipe_out_floats / 3;
+    const char* inject = std::getenv("UPX_TEST_FAIL_DOWNLOAD");   // test hook: fail the download of this item
+    const int64_t inject_at = inject ? std::atoll(inject) : -1;
 
-    // The host thread uploads chunk i+1 while the GPU transforms chunk i; a second thread waits for each
-    // chunk's kernels and downloads its owned range (a download into pageable memory blocks its caller, so it
-    // cannot share the uploading thread).  Buffer set i % 2 is reused by chunk i+2 once that download is done.
-    struct Shared {
-        std::mutex m;
-        std::condition_variable cv;
-        int64_t submitted = 0, downloaded = 0;
-        bool abort = false;
-        int rc = UPX_OK;
-        std::string err;
-    } sh;
-    std::thread downloader([&] {
-        (void)hipSetDevice(p->device);
-        for (int64_t i = 0; i < n_chunks; ++i) {
-            {
-                std::unique_lock<std::mutex> lk(sh.m);
-                sh.cv.wait(lk, [&] { return sh.submitted > i || sh.abort; });
-                if (sh.submitted <= i) return;
-            }
-            const int b = (int)(i & 1);
-            const int64_t start = i * own;
-            const int64_t cnt = (n - start < own ? n - start : own);
-            hipError_t e = hipEventSynchronize(p->ev_comp[b]);
-            float* outs[3] = {out_c, out_l, out_r};
-            for (int k = 0; k < 3 && e == hipSuccess; ++k)
-                e = hipMemcpyAsync(outs[k] + start, p->d_pipe_out[b] + k * plane, (size_t)cnt * sizeof(float),
-                                   hipMemcpyDeviceToHost, p->s_d2h);
-            if (e == hipSuccess) e = hipStreamSynchronize(p->s_d2h);
-            std::lock_guard<std::mutex> lk(sh.m);
-            if (e != hipSuccess && sh.rc == UPX_OK) {
-                sh.rc = UPX_ERR_HIP;
-                sh.err = std::string("download of a chunk failed: ") + hipGetErrorString(e);
-            }
-            sh.downloaded = i + 1;
-            sh.cv.notify_all();
-        }
-    });
-    int rc = UPX_OK;
-    std::string err;
-    for (int64_t i = 0; i < n_chunks && rc == UPX_OK; ++i) {
+    auto submit = [&](int64_t i, std::string& msg) -> int {
+        const PipeItem& it = items[(size_t)i];
         const int b = (int)(i & 1);
-        const int64_t start = i * own;
-        const bool last = i == n_chunks - 1;
-        const int64_t cnt = last ? n - start : own;
-        const int64_t t_in = n - start < cnt + spill ? n - start : cnt + spill;
-        const int64_t t_out = last ? cnt : cnt + spill;
-        if (i >= 2) {   // buffer set b: chunk i-2 must be downloaded (its kernels are then done as well)
-            std::unique_lock<std::mutex> lk(sh.m);
-            sh.cv.wait(lk, [&] { return sh.downloaded >= i - 1 || sh.rc != UPX_OK; });
-            if (sh.rc != UPX_OK) break;
-        }
-        hipError_t e = hipMemcpyAsync(p->d_pipe_in[b], stereo + 2 * start, (size_t)t_in * 2 * sizeof(float),
-                                      hipMemcpyHostToDevice, p->s_h2d);
+        hipError_t e = hipMemcpyAsync(p->d_pipe_in[b], it.src, (size_t)it.t_in * 2 * sizeof(float), hipMemcpyHostToDevice, p->s_h2d);
         if (e == hipSuccess) e = hipEventRecord(p->ev_h2d[b], p->s_h2d);
         if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, p->ev_h2d[b], 0);
         if (e != hipSuccess) {
-            rc = UPX_ERR_HIP;
-            err = std::string("upload of a chunk failed: ") + hipGetErrorString(e);
-            break;
+            msg = std::string("upload of a work item failed: ") + hipGetErrorString(e);
+            return UPX_ERR_HIP;
         }
         float* o = p->d_pipe_out[b];
-        rc = upx_process_device(p, p->d_pipe_in[b], t_in, cnt, o, o + plane, o + 2 * plane, t_out);
-        if (rc == UPX_OK && i > 0) {
+        int rc = upx_process_device(p, p->d_pipe_in[b], it.t_in, it.own, o, o + plane, o + 2 * plane, it.t_out);
+        if (rc == UPX_OK && it.seam > 0) {
             const float* q = p->d_pipe_out[b ^ 1];
-            rc = upx_seam_add_local(p, q, q + plane, q + 2 * plane, own, o, o + plane, o + 2 * plane,
-                                    spill < t_out ? spill : t_out);
+            rc = upx_seam_add_local(p, q, q + plane, q + 2 * plane, it.prev_own, o, o + plane, o + 2 * plane, it.seam);
         }
         if (rc != UPX_OK) {
-            err = g_err;
-            break;
+            msg = g_err;
+            return rc;
         }
         e = hipEventRecord(p->ev_comp[b], p->stream);
         if (e != hipSuccess) {
-            rc = UPX_ERR_HIP;
-            err = std::string("hipEventRecord: ") + hipGetErrorString(e);
-            break;
+            msg = std::string("hipEventRecord: ") + hipGetErrorString(e);
+            return UPX_ERR_HIP;
         }
-        std::lock_guard<std::mutex> lk(sh.m);
-        sh.submitted = i + 1;
-        sh.cv.notify_all();
-    }
-    {
-        std::lock_guard<std::mutex> lk(sh.m);
-        if (rc != UPX_OK) sh.abort = true;
-        sh.cv.notify_all();
-    }
-    downloader.join();
+        return UPX_OK;
+    };
+    auto complete = [&](int64_t i, std::string& msg) -> int {
+        const PipeItem& it = items[(size_t)i];
+        const int b = (int)(i & 1);
+        if (i == 0) (void)hipSetDevice(p->device);   // first call on the completer thread
+        hipError_t e = hipEventSynchronize(p->ev_comp[b]);
+        for (int k = 0; k < 3 && e == hipSuccess; ++k)
+            e = hipMemcpyAsync(it.dst[k], p->d_pipe_out[b] + k * plane, (size_t)it.own * sizeof(float), hipMemcpyDeviceToHost, p->s_d2h);
+        if (e == hipSuccess) e = hipStreamSynchronize(p->s_d2h);
+        if (e == hipSuccess && i == inject_at) e = hipErrorUnknown;
+        if (e != hipSuccess) {
+            msg = std::string("download of a work item failed: ") + hipGetErrorString(e);
+            return UPX_ERR_HIP;
+        }
+        return UPX_OK;
+    };
+    std::string err;
+    const int rc = upx::run_pipeline((int64_t)items.size(), submit, complete, err);
     (void)hipStreamSynchronize(p->stream);
-    if (rc == UPX_OK && sh.rc != UPX_OK) {
-        rc = sh.rc;
-        err = sh.err;
-    }
-    if (rc != UPX_OK) return fail((upx_status)rc, "%s", err.c_str());
+    (void)hipStreamSynchronize(p->s_d2h);
+    if (rc != UPX_OK) return fail(rc, "%s", err.c_str());
     return UPX_OK;
+}
+
+int64_t stream_chunk_default() {
+    // UPX_STREAM_CHUNK = owned samples per chunk of a long signal, 0 = never cut (one launch per track)
+    const char* env = std::getenv("UPX_STREAM_CHUNK");
+    return env ? std::atoll(env) : (1LL << 22);
+}
+}   // namespace
+
+int upx_process_chunked(upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r,
+                        int64_t chunk) {
+    if (!p || n < 0 || chunk < 1) return fail(UPX_ERR_INVALID, "upx_process_chunked: bad argument");
+    if (n == 0) return UPX_OK;
+    if (!stereo || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process_chunked: NULL buffer");
+    int64_t grid = 0, spill = 0;
+    if (!shard_geometry(p, &grid, &spill))
+        return fail(UPX_ERR_UNSUPPORTED, "the bands' hops do not share a shard grid: the signal cannot be cut into chunks");
+    std::vector<PipeItem> items;
+    if (int rc = items_of_track(p, stereo, n, out_c, out_l, out_r, chunk, true, items)) return rc;
+    return run_items(p, items);
 }
 
 int upx_process(upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r) {
     if (!p || n < 0) return fail(UPX_ERR_INVALID, "upx_process: bad argument");
     if (n == 0) return UPX_OK;
     if (!stereo || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process: NULL buffer");
-    {
-        // long signals stream through the device in chunks (uploads, kernels and downloads overlap; no limit
-        // on the length).  UPX_STREAM_CHUNK = samples per chunk, 0 = never stream.
-        const char* env = std::getenv("UPX_STREAM_CHUNK");
-        const int64_t chunk = env ? std::atoll(env) : (1LL << 22);
-        int64_t grid = 0, spill = 0;
-        if (chunk > 0 && n >= 2 * chunk && shard_geometry(p, &grid, &spill) && chunk >= 4 * spill)
-            return upx_process_chunked(p, stereo, n, out_c, out_l, out_r, chunk);
-        if (n >= (1LL << 29)) {
-            if (!shard_geometry(p, &grid, &spill))
-                return fail(UPX_ERR_INVALID, "signals of 2^29 samples or more need hops that share a shard grid");
-            return upx_process_chunked(p, stereo, n, out_c, out_l, out_r, 1LL << 26);
-        }
+    // long signals stream through the device in chunks (uploads, kernels and downloads overlap; no limit on the
+    // length); short ones are a single work item of the same pipeline
+    std::vector<PipeItem> items;
+    if (int rc = items_of_track(p, stereo, n, out_c, out_l, out_r, stream_chunk_default(), false, items)) return rc;
+    return run_items(p, items);
+}
+
+int upx_process_tracks(upx_plan* p, int32_t n_tracks, const float* const* stereo, const int64_t* n,
+                       float* const* out_c, float* const* out_l, float* const* out_r) {
+    if (!p || n_tracks < 0) return fail(UPX_ERR_INVALID, "upx_process_tracks: bad argument");
+    if (n_tracks == 0) return UPX_OK;
+    if (!stereo || !n || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process_tracks: NULL argument");
+    std::vector<PipeItem> items;
+    const int64_t chunk = stream_chunk_default();
+    for (int32_t t = 0; t < n_tracks; ++t) {
+        if (n[t] < 0) return fail(UPX_ERR_INVALID, "upx_process_tracks: track %d has a negative length", t);
+        if (n[t] == 0) continue;
+        if (!stereo[t] || !out_c[t] || !out_l[t] || !out_r[t])
+            return fail(UPX_ERR_INVALID, "upx_process_tracks: track %d has a NULL buffer", t);
+        if (int rc = items_of_track(p, stereo[t], n[t], out_c[t], out_l[t], out_r[t], chunk, false, items)) return rc;
     }
-    HIP_TRY(hipSetDevice(p->device));
-    float *d_in = nullptr, *d_out = nullptr;
-    hipError_t e = hipMalloc(&d_in, (size_t)n * 2 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * 3 * sizeof(float));
-    if (e != hipSuccess) {
-        if (d_in) (void)hipFree(d_in);
-        return fail(UPX_ERR_NOMEM, "hipMalloc for %lld samples: %s", (long long)n, hipGetErrorString(e));
-    }
-    int rc = UPX_OK;
-    do {
-        if (hipMemcpyAsync(d_in, stereo, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, p->stream) != hipSuccess) {
-            rc = fail(UPX_ERR_HIP, "H2D copy failed");
-            break;
-        }
-        rc = upx_process_device(p, d_in, n, n, d_out, d_out + n, d_out + 2 * n, n);
-        if (rc) break;
-        hipError_t c1 = hipMemcpyAsync(out_c, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, p->stream);
-        hipError_t c2 = hipMemcpyAsync(out_l, d_out + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, p->stream);
-        hipError_t c3 = hipMemcpyAsync(out_r, d_out + 2 * n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, p->stream);
-        hipError_t c4 = hipStreamSynchronize(p->stream);
-        if (c1 != hipSuccess || c2 != hipSuccess || c3 != hipSuccess || c4 != hipSuccess) {
-            hipError_t bad = c4 != hipSuccess ? c4 : (c1 != hipSuccess ? c1 : (c2 != hipSuccess ? c2 : c3));
-            rc = fail(UPX_ERR_HIP, "kernel or D2H copy failed: %s", hipGetErrorString(bad));
-        }
-    } while (0);
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
-    return rc;
+    return run_items(p, items);
 }
 
 int upx_plan_enable_timing(upx_plan* p, int enable) {
@@ -1189,8 +1227,8 @@ int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channel
         const double overall = (double)peak_out > 1e-9 ? (double)peak_out : 1e-9;   // main.py:88
         const double scale = pin / overall;                                         // main.py:90
         stats[0] = pin; stats[1] = overall; stats[2] = scale;
-        hipLaunchKernelGGL(upx_export_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_pl, d_pl + n, d_pl + 2 * n, d_st,
-                           (long long)n, scale, mode, out_format, d_o[0], d_o[1], d_o[2]);
+        hipLaunchKernelGGL(upx_export_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_pl, d_pl + n, d_pl + 2 * n, d_pcm,
+                           in_format, channels, (long long)n, scale, mode, out_format, d_o[0], d_o[1], d_o[2]);
         (void)hipEventRecord(ev[2], st);
         bool bad = false;
         for (int i = 0; i < n_out; ++i)

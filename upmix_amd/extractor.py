@@ -17,6 +17,8 @@ and float32 overlap-add) - parity is 1e-5 RMS, measured ~1e-8.
 from __future__ import annotations
 
 import ctypes as C
+import contextlib
+import threading
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -51,6 +53,10 @@ class DevicePlan:
                                              _f32p(wa), _f32p(ws), _f32p(gains)))
         self.handle = handle
         self.device = int(device)
+        # a upx_plan is not thread-safe (include/upmix_hip.h); the reference's caller is a ThreadPoolExecutor
+        # (center_extraction.py:499-501), so calls on ONE plan are serialised here; distinct plans run concurrently
+        self.lock = threading.RLock()
+        self._users = 0   # checked out of the plan cache (see _checked_out_plan)
 
     # -- whole signal, host buffers -----------------------------------------
     def process(self, stereo: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -63,8 +69,30 @@ class DevicePlan:
         if total == 0:
             return tuple(out)
         # any length: the library streams long signals through the device in chunks (upx_process_chunked)
-        _lib.check(self._lib.upx_process(self.handle, _f32p(x), total, *(_f32p(o) for o in out)))
+        with self.lock:
+            _lib.check(self._lib.upx_process(self.handle, _f32p(x), total, *(_f32p(o) for o in out)))
         return tuple(out)
+
+    def process_tracks(self, tracks: Sequence[np.ndarray]) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
+        """
+        A batch of independent tracks (float32 [T_t, 2] each) through this plan: one queue of work items, uploads /
+        kernels / downloads of consecutive tracks overlapped (upx_process_tracks).  Every track's result is
+        bit-identical to ``process(track)``.  The reference's analogue is one main.py run per file (main.py:36-80).
+        """
+        xs = [np.ascontiguousarray(t, dtype=np.float32) for t in tracks]
+        for x in xs:
+            if x.ndim != 2 or x.shape[1] != 2:
+                raise ValueError("every track must have shape [T, 2]")
+        n = len(xs)
+        outs = [[np.empty(x.shape[0], dtype=np.float32) for _ in range(3)] for x in xs]
+        if n == 0:
+            return []
+        lens = (C.c_int64 * n)(*[x.shape[0] for x in xs])
+        ins = (C.c_void_p * n)(*[x.ctypes.data for x in xs])
+        planes = [(C.c_void_p * n)(*[o[k].ctypes.data for o in outs]) for k in range(3)]
+        with self.lock:
+            _lib.check(self._lib.upx_process_tracks(self.handle, n, ins, lens, planes[0], planes[1], planes[2]))
+        return [tuple(o) for o in outs]
 
     def process_chunked(self, stereo: np.ndarray, chunk: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """The same through the streaming pipeline with an explicit chunk length (samples)."""
@@ -74,7 +102,8 @@ class DevicePlan:
         total = x.shape[0]
         out = [np.empty(total, dtype=np.float32) for _ in range(3)]
         if total:
-            _lib.check(self._lib.upx_process_chunked(self.handle, _f32p(x), total, *(_f32p(o) for o in out), int(chunk)))
+            with self.lock:
+                _lib.check(self._lib.upx_process_chunked(self.handle, _f32p(x), total, *(_f32p(o) for o in out), int(chunk)))
         return tuple(out)
 
     # -- device-resident helpers --------------------------------------------
@@ -180,8 +209,9 @@ class DevicePlan:
 
     def close(self) -> None:
         if getattr(self, "handle", None) is not None and self.handle:
-            self._lib.upx_plan_destroy(self.handle)
-            self.handle = None
+            with self.lock:
+                self._lib.upx_plan_destroy(self.handle)
+                self.handle = None
 
     def __del__(self):
         try:
@@ -219,6 +249,23 @@ class MultiBandExtractorAccu:
         self.accumL = np.zeros(block_size, dtype=np.float32)
         self.accumR = np.zeros(block_size, dtype=np.float32)
         self._plan: Optional[DevicePlan] = None
+        self._chunk_state = None   # device buffers + staging of process_stereo_chunk
+
+    def close(self) -> None:
+        """Release the device state this extractor owns (its one-band plan and the streaming buffers)."""
+        plan, self._plan = self._plan, None
+        state, self._chunk_state = self._chunk_state, None
+        if plan is not None and plan.handle:
+            if state is not None:
+                for b in state[0]:
+                    plan.free(b)
+            plan.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def gain_vector(self) -> np.ndarray:
         """float64[N/2+1]: what _band_limit does to a spectrum (:334-351)."""
@@ -242,20 +289,21 @@ class MultiBandExtractorAccu:
         one-frame job; the float32 accumulate / emit / shift is the reference's.
         """
         n, hop = self.block_size, self.hop_size
-        blk = np.zeros((n, 2), dtype=np.float32)
-        blk[:len(blkL), 0] = blkL
-        blk[:len(blkR), 1] = blkR
         plan = self._device_plan()
-        bufs = [plan.alloc(n * 8)] + [plan.alloc(n * 4) for _ in range(3)]
-        try:
+        with plan.lock:
+            if self._chunk_state is None:
+                # one frame in, three frames out: device buffers and host staging arrays live as long as the extractor
+                # (round 1 allocated and freed four device buffers per frame)
+                self._chunk_state = ([plan.alloc(n * 8)] + [plan.alloc(n * 4) for _ in range(3)],
+                                     np.zeros((n, 2), dtype=np.float32), [np.empty(n, dtype=np.float32) for _ in range(3)])
+            bufs, blk, recs = self._chunk_state
+            blk[:] = 0
+            blk[:len(blkL), 0] = blkL
+            blk[:len(blkR), 1] = blkR
             plan.h2d(bufs[0], blk)
             plan.process_device(bufs[0], n, 1, bufs[1], bufs[2], bufs[3], n)   # own_len = 1: only frame 0 exists
-            recs = [np.empty(n, dtype=np.float32) for _ in range(3)]
             for r, b in zip(recs, bufs[1:]):
                 plan.d2h(r, b)
-        finally:
-            for b in bufs:
-                plan.free(b)
         outs = []
         for acc, rec in zip((self.accumC, self.accumL, self.accumR), recs):
             acc += rec
@@ -273,6 +321,8 @@ class MultiBandExtractorAccu:
 
 
 _PLAN_CACHE: dict = {}
+_PLAN_CACHE_LOCK = threading.Lock()
+_PLAN_CACHE_SIZE = 4
 
 
 def _band_signature(b: "MultiBandExtractorAccu") -> tuple:
@@ -283,17 +333,27 @@ def _band_signature(b: "MultiBandExtractorAccu") -> tuple:
             hash(np.asarray(b.synthesis_window, dtype=np.float32).tobytes()))
 
 
-def _plan_for(band_extractors: Sequence[MultiBandExtractorAccu], device: int) -> DevicePlan:
+@contextlib.contextmanager
+def _checked_out_plan(band_extractors: Sequence[MultiBandExtractorAccu], device: int):
+    """
+    The cached DevicePlan of a band list (small LRU: plans own device memory), safe to call from several threads:
+    look-up, creation and eviction happen under one lock, and a plan that some thread is using is never evicted
+    (the cache may exceed its size for that long).
+    """
     key = (tuple(_band_signature(b) for b in band_extractors), device)
-    plan = _PLAN_CACHE.get(key)
-    if plan is None:
-        while len(_PLAN_CACHE) >= 4:                      # small LRU: plans own device memory
-            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE))).close()
-        plan = DevicePlan(band_extractors, device)
-    else:
-        del _PLAN_CACHE[key]
-    _PLAN_CACHE[key] = plan
-    return plan
+    with _PLAN_CACHE_LOCK:
+        plan = _PLAN_CACHE.pop(key, None)
+        if plan is None:
+            for k in [k for k, q in _PLAN_CACHE.items() if q._users == 0][:max(0, len(_PLAN_CACHE) - _PLAN_CACHE_SIZE + 1)]:
+                _PLAN_CACHE.pop(k).close()
+            plan = DevicePlan(band_extractors, device)
+        _PLAN_CACHE[key] = plan   # most recently used last
+        plan._users += 1
+    try:
+        yield plan
+    finally:
+        with _PLAN_CACHE_LOCK:
+            plan._users -= 1
 
 
 def extract_center_left_right_multi_band_in_memory(L: np.ndarray, R: np.ndarray, sr: float,
@@ -302,10 +362,24 @@ def extract_center_left_right_multi_band_in_memory(L: np.ndarray, R: np.ndarray,
     """
     All bands on one GPU, summed in list order in float32; returns
     (final_center, final_left, final_right).  ``sr`` is accepted and unused, as in
-    the reference (center_extraction.py:477-513).
+    the reference (center_extraction.py:477-513).  Thread-safe (the reference's own caller
+    is a thread pool): distinct band lists run on distinct plans, equal ones take turns.
     """
     stereo = np.stack([np.asarray(L, dtype=np.float32), np.asarray(R, dtype=np.float32)], axis=1)
-    return _plan_for(band_extractors, device).process(stereo)
+    with _checked_out_plan(band_extractors, device) as plan:
+        return plan.process(stereo)
+
+
+def process_tracks(tracks: Sequence[np.ndarray], band_extractors: List[MultiBandExtractorAccu], *,
+                   device: int = 0) -> List[tuple]:
+    """
+    A batch of independent stereo tracks ([T_t, 2] arrays, any real dtype) through ONE band plan on one GPU
+    (BASELINE configs[4]); returns [(center, left, right), ...] in track order, each exactly what
+    ``extract_center_left_right_multi_band_in_memory`` returns for that track alone.  The reference runs
+    main.py:36-80 once per file; here the tracks share the plan and their transfers overlap the kernels.
+    """
+    with _checked_out_plan(band_extractors, device) as plan:
+        return plan.process_tracks(tracks)
 
 
 def chain_bands(band_edges: List[float], overlap: float, window_func: Callable[[int], np.ndarray], sr: float,
