@@ -13,6 +13,7 @@
 #include "../../upmix_amd/csrc/upx_core.h"
 #include "../../upmix_amd/csrc/upx_big.h"
 #include "../../upmix_amd/csrc/upx_pipeline.h"
+#include "../../upmix_amd/csrc/upx_zoom.h"
 
 #include <atomic>
 #include <chrono>
@@ -247,4 +248,82 @@ extern "C" int emu_pipeline(long long n_items, long long fail_submit, long long 
         msg[msg_len - 1] = 0;
     }
     return order_ok ? rc : -100;
+}
+
+// ---- band-limited ("zoom") path: analysis kernel, synthesis kernel, stream seams (upx_zoom.h) ------------
+namespace {
+template <class Z>
+int run_zoom(upx::ZoomArgs a, int pairs_per_wg) {
+    using Sub = typename Z::Sub;
+    std::vector<upx::cf> tw((size_t)Z::TW_CF), ramp(upx::zoom_ramp_count(a.n, Z::P));
+    upx::fill_twiddles<Sub>(tw.data(), turn_trig);
+    upx::fill_zoom_ramp(ramp.data(), a.n, Z::P, turn_trig);
+    a.tw = tw.data();
+    a.ramp = ramp.data();
+    a.d = a.n / Z::P;
+    a.blocks_per_stream += a.blocks_per_stream & 1;
+    if (a.m_hi <= a.m_lo) return 0;
+    const int F = a.blocks_per_stream;
+    const long long n_streams = ((long long)a.m_hi - a.m_lo + 1 + F - 1) / F;
+    const int groups = a.d / Z::RG;
+    a.f0 = a.m_lo - 1;
+    const int n_frames = (int)(n_streams * F);
+    std::vector<upx::cf> y((size_t)n_frames * Z::P, upx::mk(NAN, NAN)), yc((size_t)(n_frames / 2) * Z::P, upx::mk(NAN, NAN));
+    a.y = y.data();
+    a.yc = yc.data();
+    const size_t tail = (size_t)(Z::K - 1) * a.hop;
+    std::vector<float> seam((size_t)n_streams * 3 * tail, NAN);
+    a.seam = seam.data();
+    std::vector<upx::cf> lds((size_t)Z::LDS_CF);
+    // analysis: pairs q0 .. q0 + n_frames/2 - 1
+    a.pair0 = a.m_lo / 2;
+    a.pair_end = a.pair0 + n_frames / 2;
+    a.pairs_per_wg = pairs_per_wg;   // workgroups per XCD label: the grid is 8 x this
+    for (int wg = 0; wg < 8 * pairs_per_wg; ++wg) {
+        WaveExec<16> ex;
+        ex.st.resize(Z::WG);
+        for (auto& v : lds) v = upx::mk(NAN, NAN);
+        upx::zoom_analysis_program<Z>(ex, a, lds.data(), wg);
+    }
+    a.stream0 = 0;
+    for (int role = 0; role < 2; ++role)
+        for (long long sid = 0; sid < n_streams; ++sid)
+            for (int grp = 0; grp < groups; ++grp) {
+                WaveExec<16> ex;
+                ex.st.resize(Z::WG);
+                for (auto& v : lds) v = upx::mk(NAN, NAN);
+                upx::zoom_synthesis_program<Z>(ex, a, lds.data(), (int)sid, grp, role);
+            }
+    upx::BandArgs b;
+    std::memset(&b, 0, sizeof b);
+    b.out_c = a.out_c; b.out_l = a.out_l; b.out_r = a.out_r;
+    b.t_out = a.t_out; b.m_lo = a.m_lo; b.m_hi = a.m_hi; b.blocks_per_stream = F; b.seam = a.seam;
+    for (long long g = 0; g < n_streams * (long long)tail; ++g) upx::stream_seam_add(b, (int)n_streams, (int)tail, a.hop, g);
+    return 0;
+}
+}   // namespace
+
+extern "C" int emu_zoom_band(int log2n, int k_overlap, int log2p, const float* in, long long t_in, float* out_c,
+                             float* out_l, float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
+                             const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int blocks_per_stream,
+                             int accumulate, int n_gain, int pairs_per_wg) {
+    upx::ZoomArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const upx::cf*>(in);
+    a.out_c = out_c; a.out_l = out_l; a.out_r = out_r;
+    a.w_a = w_a; a.w_s = w_s_scaled; a.gain = gain_half;
+    a.n = 1 << log2n; a.hop = a.n / k_overlap;
+    a.t_in = (int)t_in; a.t_out = (int)t_out;
+    a.j_lo = j_lo; a.j_hi = j_hi; a.m_lo = m_lo; a.m_hi = m_hi;
+    a.blocks_per_stream = blocks_per_stream; a.accumulate = accumulate;
+    a.n_gain = n_gain; a.gain_stride = a.n / 2 + 1;
+    const int d = a.n >> log2p;
+    const int rg = d >= 16 ? 16 : d;
+#define UPX_ZOOM(LP, RG, K) if (log2p == LP && rg == RG && k_overlap == K) return run_zoom<upx::ZoomCfg<LP, RG, K>>(a, pairs_per_wg);
+#define UPX_ZOOM_K(LP, RG) UPX_ZOOM(LP, RG, 2) UPX_ZOOM(LP, RG, 4) UPX_ZOOM(LP, RG, 8)
+    UPX_ZOOM_K(8, 4) UPX_ZOOM_K(8, 8) UPX_ZOOM_K(8, 16) UPX_ZOOM_K(9, 4) UPX_ZOOM_K(9, 8) UPX_ZOOM_K(9, 16)
+    UPX_ZOOM_K(10, 4) UPX_ZOOM_K(10, 8) UPX_ZOOM_K(10, 16)
+#undef UPX_ZOOM_K
+#undef UPX_ZOOM
+    return -1;
 }

@@ -412,6 +412,46 @@ def test_random_plans_vs_oracle(ux, orc):
             close(g, r)
 
 
+def test_band_limited_path_random_plans(ux, orc, monkeypatch):
+    """The two-kernel band-limited path (upx_zoom.h) forced onto every band it can carry (UPX_ZOOM=4: decimation
+    D >= 4), on random band-limited plans: STFT 2048 .. 65536, K = 2 / 4 / 8, all windows, both crossover modes,
+    repeated sizes (merged launches), ragged lengths, also streamed in chunks; 1e-5 RMS vs the oracle."""
+    monkeypatch.setenv("UPX_ZOOM", "4")
+    rng = np.random.default_rng(77)
+    wnames = ["blackman_harris", "hann", "sqrt_hann", "hamming", "blackman"]
+    n_zoom = 0
+    for trial in range(14):
+        overlap = [0.75, 0.5, 0.875, 0.75][int(rng.integers(4))]
+        wname = wnames[int(rng.integers(len(wnames)))]
+        mode = ["raised_cosine", "hard_zero"][int(rng.integers(2))]
+        n_bands = int(rng.integers(1, 5))
+        gb, ob, prev, lo = [], [], 0.0, 0.0
+        for b in range(n_bands):
+            n = [2048, 4096, 8192, 8192, 16384, 32768, 65536][int(rng.integers(7))]
+            if b and rng.random() < 0.4:
+                n = gb[-1].block_size                               # same size as the previous band: merged launch
+            top = (44100.0 / n) * float(rng.integers(20, 400))      # pass band ends between bin 20 and bin 400
+            hi = max(lo + 44100.0 / n, top)
+            width = 0.25 * hi
+            gb.append(ux.MultiBandExtractorAccu(n, overlap, ux.WINDOW_FUNCS[wname], lo, hi, 44100, mode, prev, width))
+            ob.append(orc.Band(n, overlap, lo, hi, 44100, mode, prev, width, window=orc.WINDOWS[wname]))
+            prev, lo = width, hi
+        total = int(rng.integers(1, 4 * max(b.block_size for b in gb) + 70000))
+        x = orc.synthetic_stereo(total, (9, trial))
+        ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+        plan = ux.DevicePlan(gb)
+        n_zoom += sum("zoom" in plan.band_kernel_name(i) for i in range(len(gb)))
+        outs = [plan.process(x)]
+        geo_ok = all(max(b.hop_size for b in gb) % b.hop_size == 0 for b in gb)
+        if geo_ok and total > 2:
+            outs.append(plan.process_chunked(x, int(rng.integers(1, total))))
+        plan.close()
+        for got in outs:
+            for g, r in zip(got, ref):
+                close(g, r)
+    assert n_zoom >= 10   # the plans above are band-limited: most bands must have taken the path under test
+
+
 def test_process_rank_single_gpu(ux, orc):
     """The per-rank entry of the multi-GPU path with world = 1 equals the plain call."""
     from upmix_amd import sharding
@@ -451,17 +491,22 @@ def test_pathological_signals(ux, orc):
 
 
 def test_kernel_flavours_agree(ux, orc, monkeypatch):
-    """Wide streams (default for STFT 4096 / 8192), the plain Stockham schedule (UPX_KERNEL_VARIANT=2) and the
-    8-points-per-lane kernels (=1) are different routings of the same arithmetic: each within tolerance of the
-    oracle, and within float32 rounding of one another."""
+    """Wide streams (the fused kernel for STFT 4096 / 8192), the plain Stockham schedule (UPX_KERNEL_VARIANT=2), the
+    8-points-per-lane kernels (=1) and the band-limited two-kernel path (upx_zoom.h; UPX_ZOOM = smallest decimation
+    that takes it, 0 = never) are different routings of the same arithmetic: each within tolerance of the oracle,
+    and within float32 rounding of one another."""
     x = orc.synthetic_stereo(150000, 21)
     edges, tf = [0, 120, 480, 4000], 32
     ref_bands = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, 48000, max_block_size=8192, threshold_factor=tf)
     assert sorted({b.block_size for b in ref_bands}) == [512, 4096, 8192]
     ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ref_bands)
     outs, names = {}, {}
-    for variant in ("0", "2", "1"):
-        monkeypatch.setenv("UPX_KERNEL_VARIANT", variant)
+    for variant, zoom in (("0", "0"), ("2", "0"), ("1", "0"), ("default", None), ("zoom4", "4")):
+        monkeypatch.setenv("UPX_KERNEL_VARIANT", variant if variant in "012" else "0")
+        if zoom is None:
+            monkeypatch.delenv("UPX_ZOOM", raising=False)
+        else:
+            monkeypatch.setenv("UPX_ZOOM", zoom)
         bands = gpu_chain(ux, edges, 48000, 8192, tf)
         plan = ux.DevicePlan(bands)
         names[variant] = [plan.band_kernel_name(i) for i in range(len(bands))]
@@ -472,7 +517,12 @@ def test_kernel_flavours_agree(ux, orc, monkeypatch):
     assert any("WideCfg<13, 4>" in n for n in names["0"]) and any("WideCfg<12, 4>" in n for n in names["0"])
     assert not any("Wide" in n for n in names["2"]) and any("Cfg<13, 4, 16>" in n for n in names["2"])
     assert any("Cfg<13, 4, 8>" in n for n in names["1"])
-    for v in ("2", "1"):
+    # default: the merged 8192 bands (pass band below bin 128: P = 256, D = 32) take the band-limited path,
+    # the 4096 band (bins up to 426: P = 1024, D = 4) stays fused; UPX_ZOOM=4 moves it over as well
+    assert any("zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 4>>" in n for n in names["default"])
+    assert any("WideCfg<12, 4>" in n for n in names["default"])
+    assert any("ZoomCfg<10, 4, 4>" in n for n in names["zoom4"]) and not any("Wide" in n for n in names["zoom4"])
+    for v in ("2", "1", "default", "zoom4"):
         for a, b in zip(outs["0"], outs[v]):
             assert rms(a.astype(np.float64) - b) < 1e-7
 

@@ -182,6 +182,23 @@ UPX_HD const UPX_GLOBAL T& gat(const UPX_GLOBAL T* base, unsigned voff, int c) {
     return gat(const_cast<UPX_GLOBAL T*>(base), voff, c);
 }
 
+// Element `uniform + voff` of a global array: `uniform` (elements) is the same for every lane and need not be a
+// compile-time constant (it joins the base in SGPRs), `voff` is the lane's own 32-bit element offset:
+// `global_load/store v, v_off, s[base:base+1]` without 64-bit vector arithmetic.
+template <class T>
+UPX_HD UPX_GLOBAL T& gat_u(UPX_GLOBAL T* base, long long uniform, unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    UPX_GLOBAL char* b = (UPX_GLOBAL char*)(base + uniform);
+    return *(UPX_GLOBAL T*)(b + (size_t)(voff * (unsigned)sizeof(T)));
+#else
+    return base[uniform + (long long)voff];
+#endif
+}
+template <class T>
+UPX_HD const UPX_GLOBAL T& gat_u(const UPX_GLOBAL T* base, long long uniform, unsigned voff) {
+    return gat_u(const_cast<UPX_GLOBAL T*>(base), uniform, voff);
+}
+
 // ---------------------------------------------------------------------------
 // Register DFTs, forward sign exp(-2 pi i nk/R), natural-order in and out.
 // ---------------------------------------------------------------------------
@@ -524,9 +541,10 @@ struct Stream {
             // `each2(f, g)`: g scatters into the buffer f has read.  Multi-wave streams need a barrier in
             // between; a stream inside ONE wave does not (LDS operations of a wave execute in order and every
             // scattered value depends on all 16 values read), so its executor runs f and g back to back.
+            // (captured by value: an executor may run the phases after this function has returned)
             ex.each2(
-                [&](int tid, Thread& th) { read_compute<PI>(th, lds_all + (tid / LANES) * C::PITCH, tw, tid % LANES); },
-                [&](int tid, Thread& th) { pass_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
+                [lds_all, tw](int tid, Thread& th) { read_compute<PI>(th, lds_all + (tid / LANES) * C::PITCH, tw, tid % LANES); },
+                [lds_all](int tid, Thread& th) { pass_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
             mid_passes<PI + 1>(ex, lds_all, tw);
         }
     }

@@ -22,6 +22,7 @@
 #include "upx_core.h"
 #include "upx_big.h"
 #include "upx_pipeline.h"
+#include "upx_zoom.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -248,6 +249,34 @@ __global__ __launch_bounds__(256) void upx_big_ola_kernel(upx::BigArgs a) {
     upx::big_ola<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
 
+// ---- band-limited bands: pruned analysis / residue-stream synthesis (upx_zoom.h) --------------------------
+// Z::WPE_A / WPE_S = waves per SIMD the register allocator leaves room for (4 -> 128 VGPRs, 3 -> 168): what the LDS
+// footprint of the configuration admits.
+template <class Z>
+__global__ __launch_bounds__(Z::WG, Z::WPE_A) void upx_zoom_analysis_kernel(upx::ZoomArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<true, 16> ex;
+    upx::zoom_analysis_program<Z>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+}
+// grid = (streams, residue groups, role): role 0 = Ls/Rs streams, 1 = centre streams
+template <class Z>
+__global__ __launch_bounds__(Z::WG, Z::WPE_S) void upx_zoom_synthesis_kernel(upx::ZoomArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<true, 16> ex;
+    upx::zoom_synthesis_program<Z>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+struct ZoomEntry {
+    void (*analysis)(const upx::ZoomArgs&, int n_wg, hipStream_t);
+    void (*synthesis)(const upx::ZoomArgs&, int n_streams, int n_groups, hipStream_t);
+    int (*prepare)();
+    void (*fill_tw)(upx::cf*);
+    int p, rg, k, wg, lds_bytes, tw_cf, wpe;   // lds_bytes / wpe: synthesis
+    int lds_bytes_a, wpe_a;                    // analysis
+    const char* name_analysis;
+    const char* name_synthesis;
+};
+
 struct BigEntry {
     int (*gain_bin)(int);   // order of the per-bin gain rows as the kernels read them
     int n, n1, row_wg, row_lds, row_tw_cf;
@@ -323,6 +352,49 @@ struct BigImpl {
         return BigEntry{&upx::big_gain_bin<B>, B::N, B::N1, Row::WG, kRowLds, Row::TW_CF, &chunk, &prepare, &fill_n, &fill_rows};
     }
 };
+
+template <class Z>
+struct ZoomImpl {
+    static constexpr int kLdsA = Z::LDS_A_CF * (int)sizeof(upx::cf), kLdsS = Z::LDS_S_CF * (int)sizeof(upx::cf);
+    static void analysis(const upx::ZoomArgs& a, int n_wg, hipStream_t st) {
+        hipLaunchKernelGGL((upx_zoom_analysis_kernel<Z>), dim3(n_wg), dim3(Z::WG), kLdsA, st, a);
+    }
+    static void synthesis(const upx::ZoomArgs& a, int n_streams, int n_groups, hipStream_t st) {
+        hipLaunchKernelGGL((upx_zoom_synthesis_kernel<Z>), dim3(n_streams, n_groups, 2), dim3(Z::WG), kLdsS, st, a);
+    }
+    static int prepare() {
+        int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_zoom_analysis_kernel<Z>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsA);
+        if (!e)
+            e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_zoom_synthesis_kernel<Z>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsS);
+        return e;
+    }
+    static void fill(upx::cf* tw) { upx::fill_twiddles<typename Z::Sub>(tw, turn_trig); }
+    static ZoomEntry get(const char* na, const char* ns) {
+        return ZoomEntry{&analysis, &synthesis, &prepare, &fill, Z::P, Z::RG, Z::K, Z::WG, kLdsS, Z::TW_CF, Z::WPE_S,
+                         kLdsA, Z::WPE_A, na, ns};
+    }
+};
+
+// (log2 P, residues per workgroup, K) -> kernels of the band-limited path
+const ZoomEntry* find_zoom(int log2p, int rg, int k) {
+    static const std::map<std::tuple<int, int, int>, ZoomEntry> table = [] {
+        std::map<std::tuple<int, int, int>, ZoomEntry> t;
+#define UPX_ZOOM(LP, RG, K)                                                                          \
+    t[std::make_tuple(LP, RG, K)] = ZoomImpl<upx::ZoomCfg<LP, RG, K>>::get(                          \
+        "upx_zoom_analysis_kernel<upx::ZoomCfg<" #LP ", " #RG ", " #K ">>",                           \
+        "upx_zoom_synthesis_kernel<upx::ZoomCfg<" #LP ", " #RG ", " #K ">>");
+#define UPX_ZOOM_K(LP, RG) UPX_ZOOM(LP, RG, 2) UPX_ZOOM(LP, RG, 4) UPX_ZOOM(LP, RG, 8)
+        UPX_ZOOM_K(8, 4) UPX_ZOOM_K(8, 8) UPX_ZOOM_K(8, 16) UPX_ZOOM_K(9, 4) UPX_ZOOM_K(9, 8) UPX_ZOOM_K(9, 16)
+        UPX_ZOOM_K(10, 4) UPX_ZOOM_K(10, 8) UPX_ZOOM_K(10, 16)
+#undef UPX_ZOOM_K
+#undef UPX_ZOOM
+        return t;
+    }();
+    auto it = table.find(std::make_tuple(log2p, rg, k));
+    return it == table.end() ? nullptr : &it->second;
+}
 
 constexpr int kTimingSlots = 64;          // recent upx_process_device calls whose per-band events are kept
 constexpr int kMaxFramesPerSample = 64;   // unfused path: ceil(N / hop) frames overlap one sample
@@ -404,6 +476,10 @@ struct BandState {
     int n = 0, hop = 0, k = 0, log2n = 0;
     const KernelEntry* kern = nullptr;
     const BigEntry* big = nullptr;      // STFT > 8192: four-step path
+    const ZoomEntry* zoom = nullptr;    // band-limited group: pruned analysis + residue-stream synthesis (upx_zoom.h)
+    int zoom_p = 0, zoom_d = 0;         // decimated frame length P, decimation D = N / P
+    upx::cf* d_ramp = nullptr;          // ramp seeds [D][P/16 + 4] (upx::zoom_ramp)
+    int kmax = 0;                       // highest bin with non-zero gain (leader: over the whole group)
     upx::cf* d_tw_n = nullptr;          // W_N^(k1 n2) for the big path
     int chunk_frames = 0;
     float* d_wa = nullptr;
@@ -436,6 +512,8 @@ struct upx_plan {
     size_t seam_floats = 0;
     upx::cf* d_scratch = nullptr;   // z | y | yc of the big path (shared by all big bands)
     size_t scratch_cf = 0;
+    upx::cf* d_zoom = nullptr;      // y | yc spectra between the two kernels of the band-limited path
+    size_t zoom_cf = 0;
     // streamed host calls (upx_process on long signals): copy streams, events and two rotating buffer sets
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr};
@@ -496,6 +574,35 @@ int load_rccl() {
         ncclResult_t r_ = (expr);                                                                   \
         if (r_ != ncclSuccess) return fail(UPX_ERR_RCCL, "%s: %s", #expr, g_rccl.GetErrorString(r_)); \
     } while (0)
+
+// ---- launch geometry of the band-limited path ------------------------------------------------------------------
+// frames of spectra the scratch between analysis and synthesis holds (a launch pair covers at most this many):
+// 128 MB of y + 64 MB of yc (inside the 256 MB Infinity Cache; 10 min at 48 kHz is one launch pair for every band
+// with D >= 16, and short launch pairs cost more in tails than a smaller scratch saves)
+int zoom_frames_cap(int zp) {
+    const char* env = std::getenv("UPX_ZOOM_SCRATCH_MB");
+    const long long mb = env ? std::atoll(env) : 192;
+    long long frames = mb * (1 << 20) / ((long long)zp * 12);   // P complex per frame + P/2 per frame for the pairs
+    if (frames < 64) frames = 64;
+    return (int)(frames & ~1LL);
+}
+// workgroups of the band-limited kernels one CU holds (waves per SIMD by registers; LDS: 160 KB)
+int zoom_resident(const BandState& s, bool analysis = false) {
+    const int wpe = analysis ? s.zoom->wpe_a : s.zoom->wpe, lds = analysis ? s.zoom->lds_bytes_a : s.zoom->lds_bytes;
+    int by_waves = (wpe * 256) / s.zoom->wg;
+    const int by_lds = (160 * 1024) / lds;
+    if (by_waves > by_lds) by_waves = by_lds;
+    return by_waves < 1 ? 1 : by_waves;
+}
+// streams the synthesis aims for: about UPX_ZOOM_FILL x the chip's workgroup slots, an Ls/Rs workgroup counting
+// 1 and a centre workgroup 1/2 per (stream, residue group)
+long long zoom_streams_wanted(const upx_plan* p, const BandState& s) {
+    const char* env = std::getenv("UPX_ZOOM_FILL");
+    const double fill = env ? std::atof(env) : 2.0;
+    const int groups = s.zoom_d / s.zoom->rg;
+    long long want = (long long)(fill * p->n_cu * zoom_resident(s) / (1.5 * groups));
+    return want < 1 ? 1 : want;
+}
 
 // streams the automatic launch geometry of a fused band aims for: every resident workgroup slot of the chip once
 long long max_auto_streams(const upx_plan* p, const BandState& s) {
@@ -569,54 +676,122 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&p->d_scalar, sizeof(unsigned int)));
     p->bands.resize(n_bands);
-    size_t off_w = 0, off_g = 0;
-    std::vector<size_t> band_gain_off;
+    std::vector<size_t> band_win_off, band_gain_off;
+    // pass 1: geometry, merged groups, pass band
+    {
+        size_t off_w = 0, off_g = 0;
+        for (int b = 0; b < n_bands; ++b) {
+            BandState& s = p->bands[b];
+            s.n = block_size[b];
+            s.hop = hop[b];
+            s.k = (s.n + s.hop - 1) / s.hop;   // frames covering one sample
+            s.log2n = ilog2_exact(s.n);
+            const int nb = s.n / 2 + 1;
+            // Merge with the previous band when it has the same STFT size, hop and (bit-identical) windows:
+            // the transforms are then the same linear operators and only gain -> mask runs per band.
+            s.group_leader = b;
+            if (b > 0 && !std::getenv("UPX_NO_BAND_MERGE")) {
+                const BandState& q = p->bands[b - 1];
+                if (q.n == s.n && q.hop == s.hop &&
+                    !std::memcmp(w_analysis + off_w, w_analysis + off_w - s.n, s.n * sizeof(float)) &&
+                    !std::memcmp(w_synthesis + off_w, w_synthesis + off_w - s.n, s.n * sizeof(float)))
+                    s.group_leader = q.group_leader;
+            }
+            if (s.group_leader != b) {
+                s.group_size = 0;
+                p->bands[s.group_leader].group_size += 1;
+            }
+            s.kmax = 0;
+            for (int k = 0; k < nb; ++k)
+                if (gain[off_g + k] != 0.f) s.kmax = k;
+            BandState& lead = p->bands[s.group_leader];
+            if (s.kmax > lead.kmax) lead.kmax = s.kmax;
+            band_win_off.push_back(off_w);
+            band_gain_off.push_back(off_g);
+            off_w += s.n;
+            off_g += nb;
+        }
+    }
+    // pass 2: kernel family per group.
+    //   band-limited path (upx_zoom.h): hop = N/2, N/4 or N/8, every non-zero gain below bin P/2 for a P = 256, 512 or
+    //     1024 with D = N / P >= 16: the reference's planner makes every band with a large STFT such a band;
+    //   fused streaming kernel (upx_core.h): the same hops, N <= 8192, any pass band;
+    //   unfused pipeline (upx_big.h): everything else.
+    const bool force_unfused = std::getenv("UPX_FORCE_UNFUSED") != nullptr;
+    // UPX_ZOOM = smallest decimation D = N / P for which the band-limited path is taken (0: never).  Measured on
+    // the MI355X: from D = 16 on it beats the fused kernel; below, the fused kernel's single launch wins.
+    const char* zoom_env = std::getenv("UPX_ZOOM");
+    const int zoom_min_d = zoom_env ? std::atoi(zoom_env) : 16;
     for (int b = 0; b < n_bands; ++b) {
         BandState& s = p->bands[b];
-        s.n = block_size[b];
-        s.hop = hop[b];
-        s.k = (s.n + s.hop - 1) / s.hop;   // frames covering one sample
-        s.log2n = ilog2_exact(s.n);
-        // fused streaming kernel when the hop is N/2, N/4 or N/8 and N <= 8192; otherwise the unfused path
-        s.kern = (s.n % s.hop == 0 && !std::getenv("UPX_FORCE_UNFUSED")) ? find_kernel(s.log2n, s.n / s.hop, default_variant()) : nullptr;
-        if (!s.kern) s.big = find_big(s.log2n);
-        if (int e = s.kern ? s.kern->prepare() : s.big->prepare())
+        if (s.group_size == 0) continue;
+        const bool std_hop = s.n % s.hop == 0 && (s.k == 2 || s.k == 4 || s.k == 8);
+        if (std_hop && !force_unfused && zoom_min_d > 0) {
+            int zp = 256;
+            while (zp < 2 * (s.kmax + 1)) zp *= 2;
+            const int d = s.n / zp;
+            if (zp <= 1024 && d >= 4 && d >= zoom_min_d) {
+                s.zoom = find_zoom(ilog2_exact(zp), d >= 16 ? 16 : d, s.k);
+                if (s.zoom) {
+                    s.zoom_p = zp;
+                    s.zoom_d = d;
+                }
+            }
+        }
+        if (!s.zoom && std_hop && !force_unfused) s.kern = find_kernel(s.log2n, s.n / s.hop, default_variant());
+        if (!s.zoom && !s.kern) s.big = find_big(s.log2n);
+        if (int e = s.zoom ? s.zoom->prepare() : (s.kern ? s.kern->prepare() : s.big->prepare()))
             return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
-        const int nb = s.n / 2 + 1;
-        // Merge with the previous band when it has the same STFT size, hop and (bit-identical) windows:
-        // the transforms are then the same linear operators and only gain -> mask runs per band.
-        s.group_leader = b;
-        if (b > 0 && !std::getenv("UPX_NO_BAND_MERGE")) {
-            const BandState& q = p->bands[b - 1];
-            if (q.n == s.n && q.hop == s.hop &&
-                !std::memcmp(w_analysis + off_w, w_analysis + off_w - s.n, s.n * sizeof(float)) &&
-                !std::memcmp(w_synthesis + off_w, w_synthesis + off_w - s.n, s.n * sizeof(float)))
-                s.group_leader = q.group_leader;
+        for (int m = b + 1; m < b + s.group_size; ++m) {   // members: only for reporting
+            p->bands[m].zoom = s.zoom; p->bands[m].kern = s.kern; p->bands[m].big = s.big;
+            p->bands[m].zoom_p = s.zoom_p; p->bands[m].zoom_d = s.zoom_d;
         }
-        if (s.group_leader != b) {
-            s.group_size = 0;
-            p->bands[s.group_leader].group_size += 1;
+    }
+    // pass 3: device tables
+    for (int b = 0; b < n_bands; ++b) {
+        BandState& s = p->bands[b];
+        const size_t off_w = band_win_off[b];
+        s.ring0.assign(kTimingSlots, nullptr);
+        s.ring1.assign(kTimingSlots, nullptr);
+        s.ring_used.assign(kTimingSlots, 0);
+        for (int i = 0; i < kTimingSlots; ++i) {
+            HIP_TRY(hipEventCreate(&s.ring0[i]));
+            HIP_TRY(hipEventCreate(&s.ring1[i]));
         }
+        s.ev0 = s.ring0[0];
+        s.ev1 = s.ring1[0];
+        if (s.group_size == 0) continue;   // carried by its group leader's launch
         std::vector<float> ws(s.n);
         for (int i = 0; i < s.n; ++i) ws[i] = w_synthesis[off_w + i] / (float)s.n;   // exact: N is a power of two
         HIP_TRY(hipMalloc(&s.d_wa, s.n * sizeof(float)));
         HIP_TRY(hipMalloc(&s.d_ws, s.n * sizeof(float)));
         HIP_TRY(hipMemcpy(s.d_wa, w_analysis + off_w, s.n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(s.d_ws, ws.data(), s.n * sizeof(float), hipMemcpyHostToDevice));
-        band_gain_off.push_back(off_g);
-        const int tw_key = s.log2n * 100000 + (s.kern ? s.kern->layout : 0);   // layout depends on the kernel flavour
+        // twiddle tables are shared by the bands that use the same kernel layout
+        const int tw_key = s.zoom ? 9000000 + ilog2_exact(s.zoom_p)
+                                  : s.log2n * 100000 + (s.kern ? s.kern->layout : 0);
         auto it = p->tw.find(tw_key);
         if (it == p->tw.end()) {
-            const size_t cnt = (size_t)(s.kern ? s.kern->tw_cf : s.big->row_tw_cf);
+            const size_t cnt = (size_t)(s.zoom ? s.zoom->tw_cf : (s.kern ? s.kern->tw_cf : s.big->row_tw_cf));
             std::vector<upx::cf> host(cnt);
-            if (s.kern) s.kern->fill_tw(host.data());
+            if (s.zoom) s.zoom->fill_tw(host.data());
+            else if (s.kern) s.kern->fill_tw(host.data());
             else s.big->fill_tw_rows(host.data());
             upx::cf* d = nullptr;
             HIP_TRY(hipMalloc(&d, cnt * sizeof(upx::cf)));
-            HIP_TRY(hipMemcpy(d, host.data(), cnt * sizeof(upx::cf), hipMemcpyHostToDevice));
             it = p->tw.emplace(tw_key, d).first;
+            HIP_TRY(hipMemcpy(d, host.data(), cnt * sizeof(upx::cf), hipMemcpyHostToDevice));
         }
         s.d_tw = it->second;
+        if (s.zoom) {
+            std::vector<upx::cf> host(upx::zoom_ramp_count(s.n, s.zoom_p));
+            upx::fill_zoom_ramp(host.data(), s.n, s.zoom_p, turn_trig);
+            HIP_TRY(hipMalloc(&s.d_ramp, host.size() * sizeof(upx::cf)));
+            HIP_TRY(hipMemcpy(s.d_ramp, host.data(), host.size() * sizeof(upx::cf), hipMemcpyHostToDevice));
+            // spectra between the two kernels: kZoomFrames frames of P complex (+ half as many pairs)
+            const size_t need = (size_t)zoom_frames_cap(s.zoom_p) * s.zoom_p * 3 / 2;
+            if (need > p->zoom_cf) p->zoom_cf = need;
+        }
         if (s.big) {
             // frames per chunk: 2^24 complex per scratch buffer (128 MB; z + y + yc = 320 MB).  Measured on the
             // default plan: 2^21 10.2 ms, 2^22 7.9, 2^23 7.0, 2^24 6.7, 2^25 8.3 - below, the 7 launches per chunk
@@ -632,22 +807,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             const size_t need = (size_t)s.chunk_frames * s.n * 5 / 2;   // z + y + yc/2
             if (need > p->scratch_cf) p->scratch_cf = need;
         }
-        s.ring0.assign(kTimingSlots, nullptr);
-        s.ring1.assign(kTimingSlots, nullptr);
-        s.ring_used.assign(kTimingSlots, 0);
-        for (int i = 0; i < kTimingSlots; ++i) {
-            HIP_TRY(hipEventCreate(&s.ring0[i]));
-            HIP_TRY(hipEventCreate(&s.ring1[i]));
-        }
-        s.ev0 = s.ring0[0];
-        s.ev1 = s.ring1[0];
-        off_w += s.n;
-        off_g += nb;
-    }
-    // per-bin gain lists of the (possibly merged) launches: gain[q][k] = q-th non-zero half-gain of bin k, band order
-    for (int b = 0; b < n_bands; ++b) {
-        BandState& s = p->bands[b];
-        if (s.group_size == 0) continue;
+        // per-bin gain lists of the (possibly merged) launch: gain[q][k] = q-th non-zero half-gain of bin k, band order
         const int nb = s.n / 2 + 1;
         std::vector<int> count(nb, 0);
         int slots = 1;
@@ -661,8 +821,9 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                 const float g = gain[band_gain_off[m] + k];
                 if (g != 0.f) table[(size_t)count[k]++ * nb + k] = 0.5f * g;
             }
-        {
-            // rows in the order the kernel's threads read them (natural for plain streams and whole-frame rows)
+        if (!s.zoom) {
+            // rows in the order the kernel's threads read them (natural for plain streams, whole-frame rows and
+            // the band-limited path)
             int (*order)(int) = s.kern ? s.kern->gain_bin : s.big->gain_bin;
             std::vector<float> natural(table);
             for (int q = 0; q < slots; ++q)
@@ -673,11 +834,13 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         HIP_TRY(hipMemcpy(s.d_gain, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (p->scratch_cf) HIP_TRY(hipMalloc(&p->d_scratch, p->scratch_cf * sizeof(upx::cf)));
-    // stream seam buffer of the fused kernels, sized for the largest automatic launch (no allocation, and no
-    // stream synchronisation, inside upx_process_device unless upx_plan_set_blocks_per_stream asks for more streams)
+    if (p->zoom_cf) HIP_TRY(hipMalloc(&p->d_zoom, p->zoom_cf * sizeof(upx::cf)));
+    // stream seam buffer, sized for the largest automatic launch (no allocation, and no stream synchronisation,
+    // inside upx_process_device unless upx_plan_set_blocks_per_stream or a very long signal asks for more streams)
     for (const auto& s : p->bands) {
-        if (!s.kern || s.group_size == 0) continue;
-        const size_t need = (size_t)(max_auto_streams(p, s) + s.kern->g) * 3 * (size_t)(s.k - 1) * s.hop;
+        if (s.group_size == 0 || s.big) continue;
+        const size_t streams = s.zoom ? (size_t)zoom_streams_wanted(p, s) + 1 : (size_t)(max_auto_streams(p, s) + s.kern->g);
+        const size_t need = streams * 3 * (size_t)(s.k - 1) * s.hop;
         if (need > p->seam_floats) p->seam_floats = need;
     }
     if (p->seam_floats) HIP_TRY(hipMalloc(&p->d_seam, p->seam_floats * sizeof(float)));
@@ -694,12 +857,14 @@ void upx_plan_destroy(upx_plan* p) {
         if (s.d_ws) (void)hipFree(s.d_ws);
         if (s.d_gain) (void)hipFree(s.d_gain);
         if (s.d_tw_n) (void)hipFree(s.d_tw_n);
+        if (s.d_ramp) (void)hipFree(s.d_ramp);
         for (auto e : s.ring0) if (e) (void)hipEventDestroy(e);
         for (auto e : s.ring1) if (e) (void)hipEventDestroy(e);
     }
     for (auto& kv : p->tw) (void)hipFree(kv.second);
     if (p->d_scalar) (void)hipFree(p->d_scalar);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
+    if (p->d_zoom) (void)hipFree(p->d_zoom);
     if (p->d_seam) (void)hipFree(p->d_seam);
     for (int i = 0; i < 2; ++i) {
         if (p->d_pipe_in[i]) (void)hipFree(p->d_pipe_in[i]);
@@ -818,6 +983,80 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
             s.last_wg = n_chunks;
             s.last_f = emit;
+            continue;
+        }
+        if (s.zoom) {
+            // band-limited path: per launch pair, analysis of the frames of a run of streams, then their synthesis;
+            // streams cover frames -1 .. m_hi-1 in runs of F (even); stream tails go through the seam buffer
+            const long long frames = m_hi + 1;
+            const long long want = zoom_streams_wanted(p, s);
+            long long f = s.blocks_override > 0 ? s.blocks_override : (frames + want - 1) / want;
+            if (s.blocks_override <= 0) {
+                const char* fe = std::getenv("UPX_ZOOM_F");   // experiments: frames per stream
+                if (fe) f = std::atoll(fe);
+                else if (f < 16) f = 16;
+                if (f > 64 && !fe) f = 64;
+            }
+            if (f < s.k) f = s.k;
+            f += f & 1;
+            const int cap = zoom_frames_cap(s.zoom_p);
+            if (f > cap) f = cap;
+            const long long n_streams = (frames + f - 1) / f;
+            const long long tail = (long long)(s.k - 1) * s.hop;
+            const size_t seam_need = (size_t)n_streams * 3 * tail;
+            if (seam_need > p->seam_floats) {
+                HIP_TRY(hipStreamSynchronize(p->stream));
+                if (p->d_seam) HIP_TRY(hipFree(p->d_seam));
+                p->d_seam = nullptr;
+                p->seam_floats = 0;
+                HIP_TRY(hipMalloc(&p->d_seam, seam_need * sizeof(float)));
+                p->seam_floats = seam_need;
+            }
+            upx::ZoomArgs a;
+            std::memset(&a, 0, sizeof a);
+            a.in = reinterpret_cast<const upx::cf*>(d_stereo);
+            a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
+            a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw = s.d_tw; a.ramp = s.d_ramp;
+            a.seam = p->d_seam;
+            a.n = s.n; a.d = s.zoom_d; a.hop = s.hop;
+            a.t_in = (int)t_in; a.t_out = (int)t_out;
+            a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
+            a.blocks_per_stream = (int)f;
+            a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
+            a.accumulate = b == 0 ? 0 : 1;
+            const int groups = s.zoom_d / s.zoom->rg;
+            const long long streams_per_launch = cap / f;
+            const long long slots = (long long)p->n_cu * zoom_resident(s, true);
+            if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+            int n_launches = 0;
+            for (long long s0 = 0; s0 < n_streams; s0 += streams_per_launch, ++n_launches) {
+                const long long ns = n_streams - s0 < streams_per_launch ? n_streams - s0 : streams_per_launch;
+                a.stream0 = (int)s0;
+                a.f0 = (int)(-1 + s0 * f);
+                a.y = p->d_zoom;
+                a.yc = p->d_zoom + (size_t)ns * f * s.zoom_p;
+                a.pair0 = (int)(s0 * f / 2);
+                a.pair_end = (int)((s0 + ns) * f / 2);
+                // analysis grid: every resident slot once, 8 x (workgroups per XCD label), see zoom_analysis_program
+                const long long pairs = a.pair_end - a.pair0;
+                long long per_xcd = (slots + 7) / 8;
+                if (per_xcd > (pairs + 7) / 8) per_xcd = (pairs + 7) / 8;
+                if (per_xcd < 1) per_xcd = 1;
+                a.pairs_per_wg = (int)per_xcd;
+                s.zoom->analysis(a, (int)(8 * per_xcd), p->stream);
+                s.zoom->synthesis(a, (int)ns, groups, p->stream);
+            }
+            if (n_streams > 1) {
+                upx::BandArgs sa;
+                std::memset(&sa, 0, sizeof sa);
+                sa.out_c = d_c; sa.out_l = d_l; sa.out_r = d_r;
+                sa.t_out = (int)t_out; sa.m_lo = 0; sa.m_hi = (int)m_hi; sa.blocks_per_stream = (int)f; sa.seam = p->d_seam;
+                hipLaunchKernelGGL(upx_stream_seam_add_kernel, dim3(grid_for(n_streams * tail)), dim3(256), 0, p->stream, sa,
+                                   (int)n_streams, (int)tail, s.hop);
+            }
+            if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+            s.last_wg = (int)(n_streams * groups * 2);
+            s.last_f = (int)f;
             continue;
         }
         // blocks per stream: fill every resident workgroup slot once; even (whole frame pairs), at least 8 and at
@@ -1116,8 +1355,8 @@ int upx_plan_band_info(upx_plan* p, int band, int32_t* workgroups, int32_t* thre
     if (!p || band < 0 || band >= (int)p->bands.size()) return fail(UPX_ERR_INVALID, "upx_plan_band_info: bad argument");
     const BandState& s = p->bands[band];
     if (workgroups) *workgroups = s.last_wg;
-    if (threads) *threads = s.kern ? s.kern->wg : s.big->row_wg;
-    if (lds_bytes) *lds_bytes = s.kern ? s.kern->lds_bytes : s.big->row_lds;
+    if (threads) *threads = s.zoom ? s.zoom->wg : (s.kern ? s.kern->wg : s.big->row_wg);
+    if (lds_bytes) *lds_bytes = s.zoom ? s.zoom->lds_bytes : (s.kern ? s.kern->lds_bytes : s.big->row_lds);
     if (blocks_per_stream) *blocks_per_stream = s.last_f;
     return UPX_OK;
 }
@@ -1126,7 +1365,8 @@ int upx_plan_band_kernel_name(upx_plan* p, int band, char* name, size_t n) {
     if (!p || !name || n == 0 || band < 0 || band >= (int)p->bands.size())
         return fail(UPX_ERR_INVALID, "upx_plan_band_kernel_name: bad argument");
     const BandState& s = p->bands[p->bands[band].group_leader];
-    if (s.kern) std::snprintf(name, n, "%s", s.kern->name);
+    if (s.zoom) std::snprintf(name, n, "%s", s.zoom->name_synthesis);
+    else if (s.kern) std::snprintf(name, n, "%s", s.kern->name);
     else std::snprintf(name, n, "unfused<%d>", s.n);
     return UPX_OK;
 }

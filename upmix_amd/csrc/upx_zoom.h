@@ -1,0 +1,564 @@
+// upx_zoom.h - band-limited bands: pruned ("zoom") STFT analysis and synthesis for gfx950.
+//
+// The reference's planner couples the STFT size to the band's low edge (center_extraction.py:173-197:
+// N = nextpow2(32 sr / f_low)), so whatever N is, the pass band of a band - the bins where its _band_limit gain
+// (:282-332) is non-zero - ends near bin 200: 206 of 4097 bins at N = 8192, 206 of 32 769 at N = 65 536.  Bins
+// with zero gain contribute exactly nothing (L = R = 0 there, :373-384 give C = Ls = Rs = 0), so only
+//     Z[k], |k| <= kmax      (Z = FFT_N of (L + iR) w_A; both signs because L and R are separated by symmetry)
+// has to be computed, and the inverse transforms have non-zero input only there.  With P = a power of two
+// > 2 kmax and D = N / P, split n = D m + r (residue r < D, decimated index m < P):
+//     analysis    Z[k]      = sum_r W_N^(r k) F_r[k mod P],      F_r = FFT_P over m of (x w_A)[D m + r]
+//     synthesis   y[D m + r] = IFFT_P over k of ( Y[k] W_N^(-r k) ) [m]
+// i.e. D transforms of P points plus one "ramp" multiply each way instead of a transform of N points: log2 P
+// levels instead of log2 N (9 of 13 at N = 8192, 9 of 16 at 65 536), a mask over P/2 bins instead of N/2, and - the
+// larger gain - spectra small enough (P complex per frame) to pass through memory, so the path is TWO kernels
+// with no shared register state:
+//     zoom_analysis   frame -> Z -> L/R split, gains, mask -> swap(Ls + i Rs)[P], swap(Ca + i Cb)[P] per pair
+//     zoom_synthesis  residue streams: for residue r the samples D m + r form a decimated signal whose frames
+//                     are P long with hop P/K, so one stream = P/16 lanes walking frames with the overlap-add state
+//                     in registers, exactly like the fused kernel's inverse half (upx_core.h), one per residue.
+// Neither kernel holds what the other needs (no overlap-add state in the analysis, no forward / mask state in
+// the synthesis; Ls/Rs and C streams are separate workgroups), so both fit 128 VGPRs: 4 waves per SIMD where the
+// fused kernel runs 2.  It also lifts the size limit: a frame never has to fit LDS (N = 16 384 .. 65 536 run here
+// without the scratch passes of upx_big.h whenever the band is band-limited, which the reference's planner makes them).
+//
+// Layouts.  A workgroup holds RG = min(D, 16) residues as RG sub-FFT buffers of P points (Stream<Cfg<log2 P>>):
+//     wave-local  thread t = (g = t / SL, sl = t % SL), SL = P/16: sub-FFT g lives in SL lanes of one wave
+//                 (Stockham passes through that wave's LDS region with wave-level ordering only);
+//     coalesced   thread t = (rho = t % RG, sl = t / RG): slot s is sample D (sl + SL s) + rho of the frame, so
+//                 consecutive lanes touch consecutive samples (global loads / stores of whole cache lines).
+// The first pass of a forward sub-FFT and the last pass of an inverse one are radix-16 butterflies over the 16
+// slots of ONE thread in either layout, so they run in the coalesced layout next to the global access and the
+// exchange with the wave-local passes is the ordinary Stockham scatter / read through LDS, across waves: one
+// workgroup barrier each way, as in the wide streams of upx_core.h.
+//
+// Conventions are those of upx_core.h: frame pairs (odd j, j+1) share one centre transform, inverse transforms
+// by re/im swap, overlap-add in increasing j from 0.0f, stream tails through the seam buffer
+// (stream_seam_add), bands summed in list order.
+#pragma once
+#include "upx_core.h"
+
+namespace upx {
+
+struct ZoomArgs {
+    const cf* in;          // interleaved stereo, local sample 0
+    float* out_c;
+    float* out_l;
+    float* out_r;
+    const float* w_a;      // analysis window [N]
+    const float* w_s;      // synthesis window / N [N]
+    const float* gain;     // 0.5 * band-limit gain, [n_gain][gain_stride], natural bin order (merged bands: BandArgs)
+    const cf* tw;          // compact twiddle table of the P-point sub-FFT
+    const cf* ramp;        // ramp seeds [D][P/16 + 4] (zoom_ramp): W_N^(r ks), ks = k < P/2 ? k : k - P, on the fly
+    cf* y;                 // [frames][P]: swap(Ls + i Rs) of frame j at (j - f0) P
+    cf* yc;                // [pairs][P]:  swap(Ca + i Cb) of pair q = (2q-1, 2q) at (q - (f0+1)/2) P
+    float* seam;           // [streams][3][(K-1) hop] stream tails (BandArgs::seam)
+    int n, d, hop;         // STFT size N, decimation D = N / P, hop = N / K
+    int t_in, t_out;
+    int j_lo, j_hi;        // frames that exist
+    int m_lo, m_hi;        // hop-blocks to emit
+    int blocks_per_stream; // F (even)
+    int n_gain, gain_stride;
+    int accumulate;
+    int f0;                // first frame held in y (odd)
+    int pair0, pair_end;   // analysis launch: pairs [pair0, pair_end)
+    int pairs_per_wg;      // analysis launch: workgroups per XCD (grid = 8 x this; see zoom_analysis_program)
+    int stream0;           // synthesis launch: first stream
+};
+
+template <int LOG2P_, int RG_, int K_>
+struct ZoomCfg {
+    static constexpr int LOG2P = LOG2P_;
+    static constexpr int P = 1 << LOG2P_;     // decimated frame length
+    static constexpr int RG = RG_;            // residues per workgroup
+    static constexpr int K = K_;              // frames overlapping a sample
+    static constexpr int PTS = 16;
+    static constexpr int HS = 16 / K_;        // register slots per (decimated) hop
+    using Sub = Cfg<LOG2P_, K_, 16>;
+    static constexpr int SL = Sub::LANES;     // lanes per sub-FFT
+    static constexpr int WG = RG_ * SL;
+    // Distance between the residues' buffers.  In the coalesced layout the 64 lanes of a wave are RG residues x 64/RG
+    // consecutive lanes of each; the Stockham scatter / read patterns (17 sl + r, padp(sl) + s SPITCH) spread the
+    // lanes of ONE residue over the banks, and a pitch = 64/RG (mod 32) complex interleaves the residues into the
+    // gaps (a pitch that is a multiple of 32 complex - Sub::PITCH at P = 256 - would put all RG on the same banks).
+    // (Sub::PITCH carries a spare row the fused kernel's mirror addressing needs; P + P/16 is enough here, which
+    // is what lets 4 workgroups of 4 waves, or 2 of 8, share a CU's 160 KB)
+    static constexpr int BUF = (P + P / 16 + 31) / 32 * 32 + 64 / RG_;
+    static constexpr int SP = Sub::SPITCH;
+    static constexpr int TW_CF = Sub::TW_CF;
+    static constexpr int LDS_A_CF = RG_ * BUF + TW_CF;     // analysis: sub-FFT buffers, twiddles
+    static constexpr int LDS_S_CF = LDS_A_CF + P;          // synthesis: + the staging row of the next spectrum
+    static constexpr int LDS_CF = LDS_S_CF;
+    // Waves per SIMD the 160 KB of LDS admit (at most 4: both kernels are written for 128 VGPRs); the register
+    // allocator is given exactly that many (fewer waves -> more registers, never the other way round).
+    static constexpr int waves_by_lds(int lds_cf) { return (160 * 1024 / (lds_cf * 8)) * (WG / 64) / 4; }
+    static constexpr int WPE_A = waves_by_lds(LDS_A_CF) >= 4 ? 4 : (waves_by_lds(LDS_A_CF) < 1 ? 1 : waves_by_lds(LDS_A_CF));
+    static constexpr int WPE_S = waves_by_lds(LDS_S_CF) >= 4 ? 4 : (waves_by_lds(LDS_S_CF) < 1 ? 1 : waves_by_lds(LDS_S_CF));
+    static constexpr int BPT = (P / 2 + WG - 1) / WG;   // bins per thread in the mask phase
+    static_assert(RG_ == 4 || RG_ == 8 || RG_ == 16, "residues per workgroup");
+    static_assert(WG % 64 == 0 && WG <= 1024, "whole waves");
+    static_assert(SL <= 64 && 64 % SL == 0, "a sub-FFT lives inside one wave");
+};
+
+// The ramp W_N^(r ks), ks = k < P/2 ? k : k - P, of the 16 bins k = sl + SL s a thread holds for residue r, built from
+// five table values instead of sixteen loads: ramp_s = b0 q^s with b0 = W_N^(r sl), q = W_N^(r SL); for s >= 8 the
+// signed wrap adds W_N^(-r P), folded into the seed of bit 3.  Seeds per residue: [SL] b0, then q, q^2, q^4,
+// q^8 W_N^(-r P) (row pitch SL + 4); every ramp value is a product of at most five table values.
+template <int SL>
+UPX_HD void zoom_ramp(const UPX_GLOBAL cf* seeds, int r, int sl, cf* rv) {
+    const UPX_GLOBAL cf* row = seeds + (size_t)r * (SL + 4);
+    const cf b0 = row[sl], q1 = row[SL], q2 = row[SL + 1], q4 = row[SL + 2], q8 = row[SL + 3];
+    rv[0] = b0;
+    rv[1] = cmul(b0, q1);
+    rv[2] = cmul(b0, q2);
+    rv[3] = cmul(rv[2], q1);
+    rv[4] = cmul(b0, q4);
+    rv[5] = cmul(rv[4], q1);
+    rv[6] = cmul(rv[4], q2);
+    rv[7] = cmul(rv[6], q1);
+#pragma unroll
+    for (int s = 8; s < 16; ++s) rv[s] = cmul(rv[s - 8], q8);
+}
+// x[s] = v(s) * ramp_s without holding the sixteen ramp values at once (v(s) is read when its product is formed)
+template <int SL, class V>
+UPX_HD void zoom_ramp_mul(const UPX_GLOBAL cf* seeds, int r, int sl, cf* x, V v) {
+    // (32-bit lane offsets against the uniform table base: no 64-bit vector address to keep or spill)
+    const unsigned ro = (unsigned)(r * (SL + 4));
+    const cf b0 = gat(seeds, ro + (unsigned)sl, 0), q1 = gat(seeds, ro, SL), q2 = gat(seeds, ro, SL + 1),
+             q4 = gat(seeds, ro, SL + 2), q8 = gat(seeds, ro, SL + 3);
+    auto put = [&](int s, cf rs) {
+        x[s] = cmul(v(s), rs);
+        x[s + 8] = cmul(v(s + 8), cmul(rs, q8));
+    };
+    put(0, b0);
+    put(1, cmul(b0, q1));
+    const cf r2 = cmul(b0, q2);
+    put(2, r2);
+    put(3, cmul(r2, q1));
+    const cf r4 = cmul(b0, q4);
+    put(4, r4);
+    put(5, cmul(r4, q1));
+    const cf r6 = cmul(r4, q2);
+    put(6, r6);
+    put(7, cmul(r6, q1));
+}
+
+// EAGER: all LDS reads of a radix-16 pass (inputs and twiddles, 62 registers) issued before the first multiply
+template <class Z, int PI, bool EAGER, class Ex>
+UPX_HD void zoom_mid_passes(Ex& ex, cf* lds_all, const cf* tw) {
+    using S = Stream<typename Z::Sub>;
+    using Thread = ThreadT<16>;
+    if constexpr (PI < Z::Sub::PS::n - 1) {
+        ex.each2(
+            [lds_all, tw](int tid, Thread& th) {
+                S::template read_compute<PI, EAGER>(th, lds_all + (tid / Z::SL) * Z::BUF, tw, tid % Z::SL);
+            },
+            [lds_all](int tid, Thread& th) { S::template pass_write<PI>(th, lds_all + (tid / Z::SL) * Z::BUF, tid % Z::SL); });
+        zoom_mid_passes<Z, PI + 1, EAGER>(ex, lds_all, tw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Analysis: one workgroup walks `pairs_per_wg` consecutive frame pairs.
+// Per frame:  for each residue group  { load + window + pass 0 (coalesced), scatter | B | passes 1.. (wave-local),
+//             ramp -> own LDS cells | B | sum over the group's residues into registers | B }
+//             then L/R split, gains, mask -> global.
+// ---------------------------------------------------------------------------------------------------------------
+template <class Z, class Ex>
+UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg_index) {
+    using SC = typename Z::Sub;
+    using S = Stream<SC>;
+    using PS = typename SC::PS;
+    using Thread = ThreadT<16>;
+    constexpr int P = Z::P, SL = Z::SL, RG = Z::RG, BUF = Z::BUF, LAST = PS::n - 1, BPT = Z::BPT;
+    cf* const tw = lds_all + RG * BUF;
+    const int D = a.d, N = a.n;
+    const int n_groups = D / RG;
+
+    ex.each([&](int tid, Thread&) {
+        const UPX_GLOBAL cf* src = opaque(a.tw);
+        for (int i = tid; i < Z::TW_CF; i += Z::WG) tw[i] = src[i];
+    });
+    ex.wg_barrier();
+
+    // Which pairs this workgroup transforms.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+    // one and its 4 MB L2), frames overlap K-fold, and a resident workgroup holds one frame's worth of input lines in
+    // that L2: XCD x takes the x-th eighth of the launch's pairs and its workgroups walk it side by side (pair l,
+    // l + n_l, l + 2 n_l, ... for its l-th workgroup), so the XCD's workgroups read neighbouring frames at the same
+    // time: every input line is fetched from HBM once per XCD and the K-1 other reads are L2 hits.  (A speed choice
+    // only: any placement computes the same pairs.)
+    const int n_pairs = a.pair_end - a.pair0;
+    const int per_xcd = (n_pairs + 7) / 8;
+    const int xcd = wg_index % 8, l = wg_index / 8, n_l = a.pairs_per_wg;   // pairs_per_wg: workgroups per XCD here
+    int q_stop = a.pair0 + (xcd + 1) * per_xcd;
+    if (q_stop > a.pair_end) q_stop = a.pair_end;
+    for (int q = a.pair0 + xcd * per_xcd + l; q < q_stop; q += n_l) {
+        for (int half = 0; half < 2; ++half) {
+            const int j = 2 * q - 1 + half;
+            const bool exists = j >= a.j_lo && j < a.j_hi;
+            if (exists) {
+                for (int grp = 0; grp < n_groups; ++grp) {
+                    // coalesced layout: slot s = sample D (sl + SL s) + r of the frame
+                    ex.each([&, j, grp](int tid, Thread& th) {
+                        const int rho = tid % RG, sl = tid / RG;
+                        const unsigned o = (unsigned)(D * sl + grp * RG + rho);   // slot 0 inside the frame
+                        const long long stride = (long long)D * SL;            // samples between slots (uniform)
+                        const long long base = (long long)j * a.hop;           // first sample of the frame (uniform)
+                        const UPX_GLOBAL cf* in = opaque(a.in);
+                        const UPX_GLOBAL float* w_a = opaque(a.w_a);
+                        if (base + N <= a.t_in) {
+#pragma unroll
+                            for (int s = 0; s < 16; ++s)
+                                th.x[s] = scale(gat_u(in, base + s * stride, o), gat_u(w_a, s * stride, o));
+                        } else {
+                            // zero extension past the signal (center_extraction.py:437-455): load an in-range sample,
+                            // zero the window
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) {
+                                const long long left = (long long)a.t_in - (base + s * stride);   // uniform
+                                const bool inside = (long long)o < left;
+                                const float w = gat_u(w_a, s * stride, o);
+                                const cf v = gat_u(in, inside ? base + s * stride : 0, inside ? o : 0u);
+                                th.x[s] = scale(v, inside ? w : 0.f);
+                            }
+                        }
+                        S::template pass_compute<0>(th, tw, sl);
+                        S::template pass_write<0>(th, lds_all + rho * BUF, sl);
+                    });
+                    ex.wg_barrier();
+                    // wave-local layout: sub-FFT g
+                    zoom_mid_passes<Z, 1, true>(ex, lds_all, tw);
+                    ex.each([&, grp](int tid, Thread& th) {
+                        const int g = tid / SL, sl = tid % SL;
+                        // (twiddles read at use: the ramp occupies the registers an eager radix-16 pass would take)
+                        S::template read_compute<LAST, false>(th, lds_all + g * BUF, tw, sl);
+                        // slot s holds F_r[k = sl + SL s]: times the ramp, back into the cells this thread has just read
+                        cf zv[16];
+                        zoom_ramp_mul<SL>(opaque(a.ramp), grp * RG + g, sl, zv, [&](int s) { return th.x[s]; });
+                        cf* b = lds_all + g * BUF + padp<16>(sl);
+#pragma unroll
+                        for (int s = 0; s < 16; ++s) b[s * Z::SP] = zv[s];
+                    });
+                    ex.wg_barrier();
+                    // sum over the group's residues; the sum over the groups stays in registers (bin k = tid + i WG
+                    // and its mirror P - k: two complex per bin)
+                    ex.each([&, grp](int tid, Thread& th) {
+#pragma unroll
+                        for (int i = 0; i < BPT; ++i) {
+                            const int k = tid + i * Z::WG;
+                            if (k >= P / 2) break;
+                            const cf* pa = lds_all + padp<16>(k);
+                            const cf* pb = lds_all + padp<16>(k == 0 ? 0 : P - k);
+                            cf za = lds_load(pa), zb = lds_load(pb);
+#pragma unroll
+                            for (int g = 1; g < RG; ++g) {
+                                za = za + lds_load(pa + g * BUF);
+                                zb = zb + lds_load(pb + g * BUF);
+                            }
+                            th.part[2 * i] = grp == 0 ? za : th.part[2 * i] + za;
+                            th.part[2 * i + 1] = grp == 0 ? zb : th.part[2 * i + 1] + zb;
+                        }
+                    });
+                    ex.wg_barrier();   // the buffers are free for the next scatter
+                }
+            }
+            // L/R split, gains, mask of the bins this thread has summed (no LDS access: no barrier around it)
+            ex.each([&, j, q, half, exists](int tid, Thread& th) {
+                const UPX_GLOBAL float* gain = opaque(a.gain);
+                UPX_GLOBAL cf* y = opaque(a.y) + (size_t)(j - a.f0) * P;
+                UPX_GLOBAL cf* yc = opaque(a.yc) + (size_t)(q - (a.f0 + 1) / 2) * P;
+#pragma unroll
+                for (int i = 0; i < BPT; ++i) {
+                    const int k = tid + i * Z::WG;
+                    if (k >= P / 2) break;
+                    cf c = mk(0.f, 0.f), ls = c, rs = c;
+                    if (exists) {
+                        const cf za = th.part[2 * i], zb = th.part[2 * i + 1];
+                        const cf l0 = add_conj(za, zb);      // Z[k] + conj Z[-k]        (x gain/2 = L)
+                        const cf r0 = mi_sub_conj(za, zb);   // (Z[k] - conj Z[-k]) / i  (x gain/2 = R)
+                        for (int qg = 0; qg < a.n_gain; ++qg) {
+                            const float g2 = gain[qg * a.gain_stride + k];
+                            if (g2 != 0.f) {
+                                cf l = scale(l0, g2), r = scale(r0, g2), cq, lq, rq;
+                                mask_bin(l, r, cq, lq, rq);
+                                c = c + cq; ls = ls + lq; rs = rs + rq;
+                            }
+                        }
+                        // inverse-by-swap input: Y[k] = Ls + i Rs, Y[-k] = conj(Ls) + i conj(Rs), kept re/im swapped
+                        y[k] = swap_add_i(ls, rs);
+                        if (k == 0) y[P / 2] = mk(0.f, 0.f);
+                        else y[P - k] = swap_conj_add_i(ls, rs);
+                    }
+                    if (half == 0) {
+                        th.cs[i] = c;
+                    } else {
+                        const cf ca = th.cs[i];
+                        yc[k] = swap_add_i(ca, c);
+                        if (k == 0) yc[P / 2] = mk(0.f, 0.f);
+                        else yc[P - k] = swap_conj_add_i(ca, c);
+                    }
+                }
+            });
+        }
+    }
+    ex.wg_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Synthesis: one workgroup = RG residue streams of one stream slot (frames m0 .. m0+F-1), role 0 = Ls/Rs, 1 = C.
+// Per transform:  load spectrum, ramp, pass 0 (wave-local, registers only) | B | scatter, passes 1..n-2 | B |
+//                 last pass (coalesced), window, overlap-add, emit hop.
+// ---------------------------------------------------------------------------------------------------------------
+template <class Z, int ROLE, class Ex>
+UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stream_index, int grp) {
+    constexpr int role = ROLE;   // 0: Ls/Rs streams, 1: centre streams (separate instantiations: separate register sets)
+    using SC = typename Z::Sub;
+    using S = Stream<SC>;
+    using PS = typename SC::PS;
+    using Thread = ThreadT<16>;
+    constexpr int P = Z::P, SL = Z::SL, RG = Z::RG, BUF = Z::BUF, LAST = PS::n - 1, HS = Z::HS, WG = Z::WG;
+    constexpr int NPT = P / WG;   // spectrum values a thread moves from global memory to the staging row
+    cf* const tw = lds_all + RG * BUF;
+    cf* const stage = tw + Z::TW_CF;   // the spectrum of the transform about to start, shared by the RG residues
+    const int D = a.d;
+    const int F = a.blocks_per_stream;
+    const int sid = a.stream0 + stream_index;
+    const int m0 = a.m_lo - 1 + sid * F;
+    const int stride = D * SL;   // samples between slots
+    const int n_tr = role == 0 ? F : F / 2;   // transforms of this stream: one per frame (Ls/Rs) or per pair (C)
+
+    // Spectrum of transform t (nullptr: all zero).  Ls/Rs: frame m0 + t.  C: pair (m0 + 2t, m0 + 2t + 1), m0 odd.
+    auto spec_of = [&](int t) -> const cf* {
+        if (t >= n_tr) return nullptr;
+        if (role == 0) {
+            const int j = m0 + t;
+            return j >= a.j_lo && j < a.j_hi ? a.y + (size_t)(j - a.f0) * P : nullptr;
+        }
+        const int ja = m0 + 2 * t;
+        const bool ex2 = (ja >= a.j_lo && ja < a.j_hi) || (ja + 1 >= a.j_lo && ja + 1 < a.j_hi);
+        return ex2 ? a.yc + (size_t)((ja + 1) / 2 - (a.f0 + 1) / 2) * P : nullptr;
+    };
+    // One emitted hop of a plane: slot s of a thread is sample `base + s stride` (uniform) + `o` (the thread's own).
+    struct Hop {
+        long long base;   // first sample of the hop
+        unsigned o;
+        bool emit;        // this stream emits the hop
+        bool fast;        // ... and it lies inside the planes: no per-sample checks
+    };
+    auto hop_of = [&](int tid, int j) {
+        const int rho = tid % RG, sl = tid / RG;
+        Hop h;
+        h.emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
+        h.base = (long long)j * a.hop;
+        h.o = (unsigned)(D * sl + grp * RG + rho);
+        h.fast = h.emit && h.base + a.hop <= a.t_out;
+        return h;
+    };
+    // old values of an emitted hop (band sum in list order)
+    auto load_old = [&](UPX_GLOBAL float* plane, const Hop& h, float* old) {
+#pragma unroll
+        for (int s = 0; s < HS; ++s) old[s] = 0.f;
+        if (!a.accumulate) return;
+        if (h.fast) {
+#pragma unroll
+            for (int s = 0; s < HS; ++s) old[s] = gat_u(plane, h.base + s * (long long)stride, h.o);
+        } else if (h.emit) {
+#pragma unroll
+            for (int s = 0; s < HS; ++s) {
+                const long long left = (long long)a.t_out - (h.base + s * (long long)stride);
+                if ((long long)h.o < left) old[s] = gat_u(plane, h.base + s * (long long)stride, h.o);
+            }
+        }
+    };
+    auto emit = [&](UPX_GLOBAL float* plane, const Hop& h, int s, float v) {
+        if (h.fast) {
+            gat_u(plane, h.base + s * (long long)stride, h.o) = v;
+        } else if (h.emit) {
+            const long long left = (long long)a.t_out - (h.base + s * (long long)stride);
+            if ((long long)h.o < left) gat_u(plane, h.base + s * (long long)stride, h.o) = v;
+        }
+    };
+    // old plane values of the hop(s) transform t emits -> o8[] (Ls/Rs: (old_l, old_r) per slot; C: (old of a, old of b))
+    auto fetch_old = [&](int tid, int t, cf* o8) {
+        float u[HS], v[HS];
+        if (role == 0) {
+            const Hop h = hop_of(tid, m0 + t);
+            load_old(opaque(a.out_l), h, u);
+            load_old(opaque(a.out_r), h, v);
+        } else {
+            load_old(opaque(a.out_c), hop_of(tid, m0 + 2 * t), u);
+            load_old(opaque(a.out_c), hop_of(tid, m0 + 2 * t + 1), v);
+        }
+#pragma unroll
+        for (int s = 0; s < HS; ++s) o8[s] = mk(u[s], v[s]);
+    };
+    // this thread's part of a spectrum, global memory -> registers (th.part: consumed one transform later)
+    auto fetch_spec = [&](int tid, Thread& th, const cf* spec) {
+        if (spec) {
+            const UPX_GLOBAL cf* sp = opaque(spec);
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) th.part[u] = gat(sp, (unsigned)tid, u * WG);
+        } else {
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) th.part[u] = mk(0.f, 0.f);
+        }
+    };
+    auto put_stage = [&](int tid, Thread& th) {
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) stage[tid + u * WG] = th.part[u];
+    };
+
+    // prologue: twiddles, spectrum 0 staged, spectrum 1 and the first old values in flight
+    ex.each([&](int tid, Thread& th) {
+        const UPX_GLOBAL cf* src = opaque(a.tw);
+        for (int i = tid; i < Z::TW_CF; i += WG) tw[i] = src[i];
+        fetch_spec(tid, th, spec_of(0));
+        put_stage(tid, th);
+        fetch_spec(tid, th, spec_of(1));
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            if (role == 0) th.acc_rl[s] = mk(0.f, 0.f);
+            else th.acc_c[s] = 0.f;
+        }
+    });
+    ex.wg_barrier();
+
+    // Per transform:  staged spectrum x ramp, pass 0 (wave-local, registers) | B1 | next spectrum -> stage, the one
+    // after it -> registers, scatter, passes 1..n-2 | B2 | last pass (coalesced), window, overlap-add, emit.
+    // Nothing waits for a load that was issued in the same transform except L1 hits (ramp seeds, window).
+    // The old plane values of the hop a transform emits are HBM misses.  Where the LDS footprint leaves registers
+    // to spare (3 waves per SIMD: 168 VGPRs; or the centre role) they are requested at the top of the transform,
+    // BEHIND the ramp seeds (loads return in order), and waited for at its end; otherwise at the top of the last phase.
+    constexpr bool EARLY_OLD = Z::WPE_S <= 3 || ROLE == 1;
+    for (int t = 0; t < n_tr; ++t) {
+        const bool nonzero = spec_of(t) != nullptr;
+        ex.each([&, t, nonzero](int tid, Thread& th) {
+            if (nonzero) {
+                const int g = tid / SL, sl = tid % SL;
+                const cf* sp = stage + sl;
+                zoom_ramp_mul<SL>(opaque(a.ramp), grp * RG + g, sl, th.x, [&](int s) { return lds_load(sp + s * SL); });
+            }
+            if constexpr (EARLY_OLD) {
+                UPX_SCHED_FENCE();
+                fetch_old(tid, t, th.pre);
+            }
+            if (nonzero) S::template pass_compute<0>(th, tw, tid % SL);
+        });
+        ex.wg_barrier();   // B1: the stage row and (previous transform) the sub-FFT buffers have been read by every wave
+        ex.each([&, t, nonzero](int tid, Thread& th) {
+            put_stage(tid, th);                       // spectrum t+1 (in flight since the previous transform)
+            fetch_spec(tid, th, spec_of(t + 2));
+            if (nonzero) S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL);
+        });
+        if (nonzero) {
+#if !defined(UPX_ZOOM_SYN_EAGER)
+#define UPX_ZOOM_SYN_EAGER 0   // the overlap-add state leaves no room for the twiddles of an eager pass
+#endif
+            zoom_mid_passes<Z, 1, UPX_ZOOM_SYN_EAGER != 0>(ex, lds_all, tw);
+        }
+        ex.wg_barrier();   // B2: sub-FFT buffers and the stage row complete
+        // last pass in the coalesced layout; slot s = sample D (sl + SL s) + r of the frame
+        ex.each([&, t, nonzero](int tid, Thread& th) {
+            const int rho = tid % RG, sl = tid / RG;
+            const unsigned o = (unsigned)(D * sl + grp * RG + rho);
+            // loads first, stores last: the old plane values of the hop(s) about to be emitted (band sum in list
+            // order; HBM misses that the last pass and the overlap-add below cover in part) and the window
+            cf old[HS];
+            if constexpr (EARLY_OLD) {
+#pragma unroll
+                for (int s = 0; s < HS; ++s) old[s] = th.pre[s];
+            } else {
+                fetch_old(tid, t, old);
+            }
+            UPX_SCHED_FENCE();   // issued before anything below
+            if (nonzero) {
+                S::template read_compute<LAST, false>(th, lds_all + rho * BUF, tw, sl);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) th.x[s] = mk(0.f, 0.f);
+            }
+            UPX_SCHED_FENCE();
+            // (the window only now: sixteen more live registers during the last pass would not fit next to the
+            // overlap-add state; L1 hits)
+            const UPX_GLOBAL float* w_s = opaque(a.w_s);
+            float w[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) w[s] = gat_u(w_s, s * (long long)stride, o);
+            UPX_SCHED_FENCE();
+            if (role == 0) {
+                const Hop h = hop_of(tid, m0 + t);
+                UPX_GLOBAL float* out_l = opaque(a.out_l);
+                UPX_GLOBAL float* out_r = opaque(a.out_r);
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    th.acc_rl[s] = th.acc_rl[s] + scale(th.x[s], w[s]);   // swapped output: Ls = x.y, Rs = x.x
+#pragma unroll
+                for (int s = 0; s < HS; ++s) {
+                    emit(out_l, h, s, old[s].x + th.acc_rl[s].y);
+                    emit(out_r, h, s, old[s].y + th.acc_rl[s].x);
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) th.acc_rl[s] = s + HS < 16 ? th.acc_rl[s + HS] : mk(0.f, 0.f);
+            } else {
+                UPX_GLOBAL float* out_c = opaque(a.out_c);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const Hop h = hop_of(tid, m0 + 2 * t + half);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)   // swapped output: c_a = x.y, c_b = x.x
+                        th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w[s];
+#pragma unroll
+                    for (int s = 0; s < HS; ++s) emit(out_c, h, s, (half == 0 ? old[s].x : old[s].y) + th.acc_c[s]);
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) th.acc_c[s] = s + HS < 16 ? th.acc_c[s + HS] : 0.f;
+                }
+            }
+        });
+    }
+    // what is left in the accumulators belongs to the K-1 blocks after this stream
+    ex.each([&](int tid, Thread& th) {
+        const int rho = tid % RG, sl = tid / RG;
+        const size_t tail = (size_t)(Z::K - 1) * a.hop;
+        UPX_GLOBAL float* seam = opaque(a.seam) + (size_t)sid * 3 * tail + (D * sl + grp * RG + rho);
+#pragma unroll
+        for (int s = 0; s < 16 - HS; ++s) {
+            if (role == 0) {
+                seam[1 * tail + (size_t)s * stride] = th.acc_rl[s].y;
+                seam[2 * tail + (size_t)s * stride] = th.acc_rl[s].x;
+            } else {
+                seam[(size_t)s * stride] = th.acc_c[s];
+            }
+        }
+    });
+    ex.wg_barrier();
+}
+
+template <class Z, class Ex>
+UPX_HD void zoom_synthesis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int stream_index, int grp, int role) {
+    if (role == 0) zoom_synthesis_role<Z, 0>(ex, a, lds_all, stream_index, grp);
+    else zoom_synthesis_role<Z, 1>(ex, a, lds_all, stream_index, grp);
+}
+
+// Host-side helper: the ramp seeds of zoom_ramp, [D][P/16 + 4] (double precision -> float).
+template <class TrigFn>
+inline void fill_zoom_ramp(cf* seeds, int n, int p, TrigFn trig) {
+    const int d = n / p, sl_n = p / 16;
+    auto w = [&](long long num) {   // W_N^num
+        num %= n;
+        if (num < 0) num += n;
+        double c, s;
+        trig((double)num / (double)n, c, s);
+        return mk((float)c, (float)-s);
+    };
+    for (int r = 0; r < d; ++r) {
+        cf* row = seeds + (size_t)r * (sl_n + 4);
+        for (int sl = 0; sl < sl_n; ++sl) row[sl] = w((long long)r * sl);
+        row[sl_n] = w((long long)r * sl_n);
+        row[sl_n + 1] = w((long long)r * sl_n * 2);
+        row[sl_n + 2] = w((long long)r * sl_n * 4);
+        row[sl_n + 3] = w((long long)r * sl_n * 8 - (long long)r * p);
+    }
+}
+inline size_t zoom_ramp_count(int n, int p) { return (size_t)(n / p) * (p / 16 + 4); }
+
+}   // namespace upx
