@@ -2,23 +2,28 @@
 """
 bench.py - headline benchmark: stereo Msamples/s upmixed (6 bands, STFT <= 8192).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--workload c3|default|c4share|batch]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (all 6 bands of BASELINE.json configs[2]:
-10 min of 48 kHz stereo, edges 0/30/120/480/1920/7680 Hz, STFT sizes
-[8192,8192,8192,4096,1024,256], Blackman-Harris, 75 % overlap, raised-cosine
-crossovers) over synthetic stereo already resident in HBM.  With N > 1 ranks the
-signal is N x 10 min, time-sharded on the hop_max grid (one 10-min shard per
-GPU, weak scaling) and every step ends with the single RCCL all-reduce of the
-overlap-add seam.  torch.distributed (gloo) is used only
-for the rendezvous, barriers and the max-over-ranks of the wall time; all GPU
-work goes through libupmix_hip.so.
+A "step" is one pass of the hot path over synthetic stereo already resident in HBM.  Workloads:
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+  c3       (default; the line the driver records) BASELINE.json configs[2]: 10 min of 48 kHz stereo, 6 bands, edges
+           0/30/120/480/1920/7680 Hz, STFT [8192,8192,8192,4096,1024,256], Blackman-Harris, 75 % overlap, raised-cosine
+           crossovers.  N > 1 ranks: N x 10 min, time-sharded on the hop_max grid (one shard per GPU, weak scaling),
+           every step ends with the single RCCL all-reduce of the overlap-add seam.
+  default  the same signal through the reference's own default plan (center_extraction.py:555, main.py:62:
+           STFT [65536,65536,16384,4096,1024,256]) - what a caller who does not cap the STFT size runs.
+  c4share  one GPU's share of configs[3]: 15 min of 96 kHz stereo (86.4 M samples), STFT [8192 x4, 2048, 512];
+           N > 1 ranks: the time-sharded 2 h (at N = 8) signal with the RCCL seam.
+  batch    configs[4]: 8 independent 5-min 48 kHz tracks per GPU (64 on 8 GPUs), C3 plan, replicas only (no
+           communication); `value` = tracks resident in HBM, the PCIe-inclusive upx_process_tracks rate is in `e2e`.
+
+torch.distributed (gloo) is used only for the rendezvous, barriers and the max-over-ranks of the wall time; all GPU
+work goes through libupmix_hip.so.  Prints ONE JSON line on rank 0 (fields: README / DESIGN.md section 7).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,12 +34,21 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SR = 48000
-SECONDS = 600
 EDGES = [0, 30, 120, 480, 1920, 7680]
-MAX_STFT = 8192
-HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ALGO_BYTES_PER_SAMPLE_BAND = 20  # 8 B stereo in + 12 B Ls/C/Rs out, per band
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+VALU_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32 vector peak (SURVEY.md 8(d) secondary ceiling)
+ALGO_BYTES_IN, ALGO_BYTES_OUT = 8, 12   # per band 8 B stereo in + 12 B Ls/C/Rs out = 20 B per sample
+KERNEL_SOURCES = ["upmix_amd/csrc/upx_core.h", "upmix_amd/csrc/upx_zoom.h", "upmix_amd/csrc/upx_big.h",
+                  "upmix_amd/csrc/upx_lib.hip"]
+
+WORKLOADS = {
+    #          sr     seconds  max_stft  BASELINE config
+    "c3":      (48000, 600,    8192,     "BASELINE configs[2]"),
+    "default": (48000, 600,    65536,    "configs[2] signal, reference default plan (max STFT 65536)"),
+    "c4share": (96000, 900,    8192,     "one GPU's share of BASELINE configs[3] (2 h at 96 kHz over 8 GPUs)"),
+    "batch":   (48000, 300,    8192,     "BASELINE configs[4] (8 tracks of 5 min per GPU)"),
+}
+TRACKS_PER_GPU = 8
 
 
 def synth(total, seed):
@@ -47,30 +61,38 @@ def synth(total, seed):
     return x
 
 
-def cpu_baseline(target_seconds=15.0):
+def kernel_sources_sha():
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(sr, max_stft, target_seconds=15.0):
     """
     The oracle in the reference's scheduling shape (ThreadPoolExecutor(), one task per band, sequential
     frame loop per band) on a bounded prefix of the same workload: a 10 s calibration slice sizes the
     timed sample so that it costs about `target_seconds` of CPU wall time.
     """
     from oracle import upmix_oracle as orc
-    bands = orc.plan_bands(EDGES, 0.75, orc.win_blackman_harris, SR, max_block_size=MAX_STFT)
+    bands = orc.plan_bands(EDGES, 0.75, orc.win_blackman_harris, sr, max_block_size=max_stft)
 
     def run(seconds):
-        total = int(SR * seconds)
+        total = int(sr * seconds)
         x = synth(total, 2).astype(np.float64)
         t0 = time.perf_counter()
         orc.extract_multi_band_threadpool(x[:, 0], x[:, 1], bands)
         return total, time.perf_counter() - t0
 
     total, dt = run(10.0)
-    sample_seconds = float(min(SECONDS, max(10.0, 10.0 * target_seconds / max(dt, 1e-3))))
+    sample_seconds = float(min(600, max(10.0, 10.0 * target_seconds / max(dt, 1e-3))))
     if sample_seconds > 10.0:
         total, dt = run(sample_seconds)
     else:
         sample_seconds = 10.0
     # the same frame loops one band after the other (no thread pool): SURVEY 8(d) asks for both
-    xs = synth(int(SR * 10.0), 2).astype(np.float64)
+    xs = synth(int(sr * 10.0), 2).astype(np.float64)
     t0 = time.perf_counter()
     orc.extract_multi_band(xs[:, 0], xs[:, 1], bands, per_band=orc.band_process_streaming)
     serial = len(xs) / (time.perf_counter() - t0) / 1e6
@@ -84,14 +106,62 @@ def cpu_baseline(target_seconds=15.0):
 
 
 def load_pmc_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary, if present."""
+    """
+    HBM bytes per launch of `kernel_tag` from the committed rocprofv3 PMC summary (profiles/pmc_traffic.json) - only
+    if that summary was collected from the kernel sources that are running now (their hash is stored with it).
+    """
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as fh:
             rec = json.load(fh)
-        return rec.get(kernel_tag, {}).get("hbm_bytes_per_launch")
     except Exception:
-        return None
+        return None, "no profiles/pmc_traffic.json"
+    sha = rec.get("_kernel_sources_sha256_16")
+    if sha != kernel_sources_sha():
+        return None, f"profiles/pmc_traffic.json was collected from other kernel sources ({sha}); re-run scripts/pmc.sh"
+    v = rec.get(kernel_tag, {}).get("hbm_bytes_per_launch")
+    return v, (None if v is not None else "kernel not in profiles/pmc_traffic.json")
+
+
+def e2e_rates(ux, plan, bands, sr, nominal):
+    """PCIe-inclusive rates of the host-buffer entry points on this workload's signal (never `value`)."""
+    from upmix_amd import wav as _wav  # noqa: F401
+    out = {}
+    x = synth(nominal, 2)
+
+    def timed(fn, reps=3):
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        return best
+
+    # upx_process (streamed in chunks: upload / kernels / download overlap) into arrays that were touched before ...
+    lib, check = plan._lib, __import__("upmix_amd")._lib.check
+    f32p = __import__("upmix_amd")._lib.f32p
+    warm = [np.zeros(nominal, dtype=np.float32) for _ in range(3)]
+    run = lambda outs: check(lib.upx_process(plan.handle, x.ctypes.data_as(f32p), nominal, *(o.ctypes.data_as(f32p) for o in outs)))  # noqa: E731
+    run(warm)
+    dt = timed(lambda: run(warm))
+    out["upx_process_warm_buffers"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1)}
+    # ... and into fresh NumPy arrays (the kernel has to fault in and zero the new pages)
+    dt = timed(lambda: run([np.empty(nominal, dtype=np.float32) for _ in range(3)]))
+    out["upx_process_fresh_arrays"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1)}
+    # WAV pipeline: PCM16 in, decode + all bands + peak scale + stereo_sum layout + quantisation on the device, PCM16 out
+    pcm = np.clip(np.rint(x * 32767.0), -32768, 32767).astype("<i2")
+    del x
+    fn = lambda: plan.wav_pipeline(pcm, 16, 2, nominal, "stereo_sum", 16)  # noqa: E731
+    fn()
+    dt = timed(fn)
+    t = plan.wav_pipeline_times_ms()
+    out["upx_wav_pipeline_pcm16_stereo_sum"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1),
+                                                "h2d_ms": round(t["h2d"], 2), "device_ms": round(t["device"], 2),
+                                                "d2h_ms": round(t["d2h"], 2)}
+    out["note"] = ("pageable host buffers; best of 3; PCIe-inclusive, reported beside `value` (which is HBM-resident), "
+                   "SURVEY.md 8(d)")
+    return out
 
 
 def main():
@@ -99,8 +169,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--seconds", type=float, default=SECONDS, help="audio per GPU (default: 600 = configs[2])")
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--seconds", type=float, default=None, help="audio per GPU / per track (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,102 +201,144 @@ def main():
               file=sys.stderr)
     local_rank = local_rank % n_dev
 
-    nominal = int(SR * args.seconds)
-    bands = ux.chain_bands(EDGES, 0.75, ux.make_blackman_harris, SR, max_block_size=MAX_STFT, verbose=False,
+    sr, seconds, max_stft, cfg_name = WORKLOADS[args.workload]
+    if args.seconds is not None:
+        seconds = args.seconds
+    nominal = int(sr * seconds)
+    batch = args.workload == "batch"
+    bands = ux.chain_bands(EDGES, 0.75, ux.make_blackman_harris, sr, max_block_size=max_stft, verbose=False,
                            device=local_rank)
     plan = ux.DevicePlan(bands, device=local_rank)
-    geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
-    # N ranks: one signal of N x 10 min cut on the shard grid; rank g owns shard g (+ right halo, + spill)
-    shards = geo.plan(nominal * world, world)
-    shard = shards[rank]
-    own, t_in, t_out = shard.own_len, shard.t_in, shard.t_out
-    spill = geo.spill if world > 1 else 0
-
-    # synthetic stereo: shard g = seed (2, g) (N=1: seed 2); right halo = head of the next shard
-    x = synth(own, 2 if world == 1 else (2, rank))
-    if t_in > own:
-        x = np.concatenate([x, synth(shards[rank + 1].own_len, (2, rank + 1))[:t_in - own]])
-    d_in = plan.alloc(t_in * 8)
-    d_out = [plan.alloc((own + spill) * 4) for _ in range(3)]
-    plan.h2d(d_in, x)
-    del x
+    n_bands = len(bands)
 
     comm = None
-    if world > 1 and os.environ.get("UPX_BENCH_REHEARSAL") == "1":
-        # Rehearsal on a box with fewer GPUs than ranks (ranks share a device, which RCCL refuses): the seam goes
-        # through host memory + gloo.  Exercises everything but RCCL; the JSON line says so and is not a bench result.
-        class _GlooSeam:
-            def exchange(self, planes, own_len, spill_):
-                import torch
-                host = [np.empty(own_len + spill_, dtype=np.float32) for _ in range(3)]
-                for h, d in zip(host, planes):
-                    plan.d2h(h, d)
-                seam = sharding.pack_seam(host, shard, world, spill_)
-                t = torch.from_numpy(seam)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                sharding.apply_seam(host, shard, t.numpy())
-                for h, d in zip(host, planes):
-                    plan.h2d(d, h)
+    if batch:
+        # replicas only: rank r owns tracks r, r + world, ... of TRACKS_PER_GPU x world tracks (seed (4, track))
+        from upmix_amd import batch as _batch
+        mine = _batch.assign_tracks(TRACKS_PER_GPU * world, rank, world)
+        own = t_in = t_out = nominal
+        d_tracks = []
+        for t in mine:
+            d = plan.alloc(nominal * 8)
+            plan.h2d(d, synth(nominal, (4, t)))
+            d_tracks.append(d)
+        d_out = [plan.alloc(nominal * 4) for _ in range(3)]
+        samples_per_step_rank = nominal * len(mine)
 
-            def close(self):
-                pass
-        comm = _GlooSeam()
-    elif world > 1:
-        comm = sharding.RcclSeam(plan, rank, world, broadcast=lambda b: sharding.broadcast_bytes_gloo(dist, b))
+        def step():
+            for d in d_tracks:
+                plan.process_device(d, nominal, nominal, d_out[0], d_out[1], d_out[2], nominal)
+        calls_per_step = len(d_tracks)
+    else:
+        geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
+        # N ranks: one signal of N x `seconds` cut on the shard grid; rank g owns shard g (+ right halo, + spill)
+        shards = geo.plan(nominal * world, world)
+        shard = shards[rank]
+        own, t_in, t_out = shard.own_len, shard.t_in, shard.t_out
+        spill = geo.spill if world > 1 else 0
+        # synthetic stereo: shard g = seed (2, g) (N=1: seed 2); right halo = head of the next shard
+        x = synth(own, 2 if world == 1 else (2, rank))
+        if t_in > own:
+            x = np.concatenate([x, synth(shards[rank + 1].own_len, (2, rank + 1))[:t_in - own]])
+        d_in = plan.alloc(t_in * 8)
+        d_out = [plan.alloc((own + spill) * 4) for _ in range(3)]
+        plan.h2d(d_in, x)
+        del x
+        samples_per_step_rank = own
+        if world > 1 and os.environ.get("UPX_BENCH_REHEARSAL") == "1":
+            # Rehearsal on a box with fewer GPUs than ranks (ranks share a device, which RCCL refuses): the seam goes
+            # through host memory + gloo.  Exercises everything but RCCL; the JSON line says so and is not a result.
+            class _GlooSeam:
+                def exchange(self, planes, own_len, spill_):
+                    import torch
+                    host = [np.empty(own_len + spill_, dtype=np.float32) for _ in range(3)]
+                    for h, d in zip(host, planes):
+                        plan.d2h(h, d)
+                    seam = sharding.pack_seam(host, shard, world, spill_)
+                    t = torch.from_numpy(seam)
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                    sharding.apply_seam(host, shard, t.numpy())
+                    for h, d in zip(host, planes):
+                        plan.h2d(d, h)
+
+                def close(self):
+                    pass
+            comm = _GlooSeam()
+        elif world > 1:
+            comm = sharding.RcclSeam(plan, rank, world, broadcast=lambda b: sharding.broadcast_bytes_gloo(dist, b))
+
+        def step():
+            plan.process_device(d_in, t_in, own, d_out[0], d_out[1], d_out[2], t_out)
+            if comm is not None:
+                comm.exchange(d_out, own, spill)
+        calls_per_step = 1
 
     def barrier():
         plan.sync()
         if dist is not None:
             dist.barrier()
 
-    def step():
-        plan.process_device(d_in, t_in, own, d_out[0], d_out[1], d_out[2], t_out)
-        if comm is not None:
-            comm.exchange(d_out, own, spill)
-
     for _ in range(args.warmup):
         step()
     plan.enable_timing(True)
-    band_ms = np.zeros(len(bands))
     barrier()
     t0 = time.perf_counter()
-    # HIP events on the plan's stream around each band kernel, kept per call by the library (64 calls) and read
-    # after the loop: no synchronisation inside the timed region
-    for i in range(args.steps):
+    # HIP events on the plan's stream around every kernel launch group, kept per call by the library (64 calls) and
+    # read after the loop: no synchronisation, and no reads, inside the timed region
+    for _ in range(args.steps):
         step()
-        if (i + 1) % 64 == 0 and i + 1 < args.steps:
-            band_ms += plan.band_times_sum_ms(64)
     plan.sync()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if args.steps % 64 or args.steps == 0:
-        band_ms += plan.band_times_sum_ms(args.steps % 64) if args.steps % 64 else 0
-    else:
-        band_ms += plan.band_times_sum_ms(64)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    band_ms /= max(args.steps, 1)
+    n_calls = min(64, args.steps * calls_per_step)          # the most recent timed process_device calls
+    per_call = plan.band_times_calls_ms(n_calls) if n_calls else np.zeros((0, n_bands), np.float32)
+    band_ms = per_call.mean(axis=0) if n_calls else np.zeros(n_bands)
+    ana_sum, syn_sum = plan.band_phase_times_sum_ms(n_calls) if n_calls else (np.zeros(n_bands), np.zeros(n_bands))
+    # median over steps of the step's kernel time (3 warm-ups + median of 10): the last <= 10 steps
+    step_ms = per_call.sum(axis=1)
+    if calls_per_step > 1 and len(step_ms) >= calls_per_step:
+        step_ms = step_ms[len(step_ms) % calls_per_step:].reshape(-1, calls_per_step).sum(axis=1)
+    median_ms = float(np.median(step_ms[-10:])) if len(step_ms) else None
 
     if rank == 0:
-        total_samples = nominal * world
+        total_samples = samples_per_step_rank * world if not batch else nominal * TRACKS_PER_GPU * world
         ms_per_step = elapsed / args.steps * 1e3
         value = total_samples * args.steps / elapsed / 1e6
-        # launches: one per group of merged bands (same STFT size / hop / windows); the dominant kernel is the
-        # launch with the largest time.  Algorithmic bytes of a launch = 20 B x samples x bands it carries.
         sizes = [b.block_size for b in bands]
         groups = {}
-        for i in range(len(bands)):
+        for i in range(n_bands):
             leader, size = plan.band_group(i)
             groups[leader] = size
-        dom = max(groups, key=lambda g: band_ms[g])
-        dom_ms = float(band_ms[dom])
-        algo_bytes = ALGO_BYTES_PER_SAMPLE_BAND * own * groups[dom]
-        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-        tag = plan.band_kernel_name(dom)   # kernel symbol as rocprofv3 prints it
+        # one entry per KERNEL: single-kernel launches carry the band's 20 B per sample, the two kernels of a
+        # band-limited launch its 8 B (analysis reads the input) and 12 B (synthesis writes Ls/C/Rs); merged bands
+        # multiply.  `ms` = average launch time per process_device call (HIP events, same stream as the kernels).
+        launches = []
+        for g, n in sorted(groups.items()):
+            label = f"bands {g}..{g + n - 1} (STFT {sizes[g]})"
+            a_name = plan.band_phase_kernel_name(g, 0)
+            if a_name:
+                launches.append({"kernel": a_name, "bands": label, "ms": float(ana_sum[g]) / n_calls,
+                                 "algo_bytes": ALGO_BYTES_IN * own * n})
+                launches.append({"kernel": plan.band_phase_kernel_name(g, 1), "bands": label,
+                                 "ms": float(syn_sum[g]) / n_calls, "algo_bytes": ALGO_BYTES_OUT * own * n})
+            else:
+                launches.append({"kernel": plan.band_kernel_name(g), "bands": label, "ms": float(band_ms[g]),
+                                 "algo_bytes": (ALGO_BYTES_IN + ALGO_BYTES_OUT) * own * n})
+        for L in launches:
+            L["GBps"] = round(L["algo_bytes"] / (L["ms"] * 1e-3) / 1e9, 1) if L["ms"] > 0 else None
+            L["frac"] = round(L["GBps"] / HBM_PEAK_GBPS, 4) if L["GBps"] else None
+            L["ms"] = round(L["ms"], 4)
+        dom = max(launches, key=lambda L: L["ms"])
+        traffic, traffic_note = load_pmc_traffic(dom["kernel"])
+        kernel_ms = float(band_ms.sum())
+        flops_per_sample = 50.0 * sum(np.log2(n) for n in sizes) + 80.0 * n_bands
+        calls_samples = own                                                            # samples per process_device call
         out = {
             "metric": "stereo Msamples/sec upmixed (6-band, STFT<=8192)",
             "value": round(value, 2),
@@ -239,34 +353,70 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[2]: {args.seconds:g} s of 48 kHz stereo per GPU, 6 bands "
+                "workload": f"{cfg_name}: " + (f"{TRACKS_PER_GPU} tracks of " if batch else "") +
+                            f"{seconds:g} s of {sr // 1000} kHz stereo per GPU, 6 bands "
                             f"(edges 0/30/120/480/1920/7680 Hz), STFT {sizes}, Blackman-Harris 75% WOLA, "
                             f"raised-cosine crossovers XO 0.25, export Ls/C/Rs planes",
-                "samples_per_gpu": nominal,
-                "x_realtime": round(total_samples / SR / (elapsed / args.steps), 1),
+                "name": args.workload,
+                "samples_per_gpu": samples_per_step_rank,
+                "x_realtime": round(total_samples / sr / (elapsed / args.steps), 1),
                 "parallelism": "1 GPU" if world == 1 else (
-                    f"time-sharded x{world}, one RCCL seam all-reduce per step"
+                    (f"{world} replicas, tracks rank::world, no communication" if batch else
+                     f"time-sharded x{world}, one RCCL seam all-reduce per step")
                     if os.environ.get("UPX_BENCH_REHEARSAL") != "1" else f"REHEARSAL x{world} (host seam, shared device) - not a result"),
             },
+            "median_kernel_ms_per_step": None if median_ms is None else round(median_ms, 4),
             "roofline": {
                 "bound": "hbm",
-                "kernel": tag,
-                "achieved": round(achieved, 1),
+                "kernel": dom["kernel"],
+                "achieved": dom["GBps"],
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": load_pmc_traffic(tag),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "bands_in_launch": groups[dom],
-                "avg_launch_ms": round(dom_ms, 4),
+                "frac": dom["frac"],
+                "traffic": traffic,
+                "traffic_note": traffic_note,
+                "achieved_traffic_GBps": None if not traffic else round(traffic / (dom["ms"] * 1e-3) / 1e9, 1),
+                "algorithmic_bytes_per_launch": dom["algo_bytes"],
+                "bands_in_launch": dom["bands"],
+                "avg_launch_ms": dom["ms"],
+                "limiter": "not HBM: wave issue + LDS / memory latency at 2-4 waves per SIMD (DESIGN.md 5, 8); the "
+                           "`valu` object is the ceiling that binds",
             },
-            "per_launch_ms": {f"bands {g}..{g + n - 1} (STFT {sizes[g]})": round(float(band_ms[g]), 4)
-                              for g, n in sorted(groups.items())},
-            "all_bands_algorithmic_GBps": round(ALGO_BYTES_PER_SAMPLE_BAND * len(bands) * own
-                                                / (float(band_ms.sum()) * 1e-3) / 1e9, 1),
+            "launches": launches,
+            "all_bands_algorithmic_GBps": round((ALGO_BYTES_IN + ALGO_BYTES_OUT) * n_bands * calls_samples
+                                                / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else None,
+            "all_bands_frac": round((ALGO_BYTES_IN + ALGO_BYTES_OUT) * n_bands * calls_samples
+                                    / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if kernel_ms > 0 else None,
+            "valu": {
+                "flops_per_sample": round(flops_per_sample, 1),
+                "formula": "50 * sum_b log2 N_b + 80 * bands (SURVEY.md 8(d): algorithmic, full-size transforms)",
+                "achieved": round(flops_per_sample * calls_samples / (kernel_ms * 1e-3) / 1e12, 2) if kernel_ms > 0 else None,
+                "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(flops_per_sample * calls_samples / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4) if kernel_ms > 0 else None,
+            },
+            "kernel_sources_sha256_16": kernel_sources_sha(),
         }
+        if world == 1 and not args.no_e2e:
+            try:
+                if batch:
+                    tracks = [synth(nominal, (4, t)) for t in range(TRACKS_PER_GPU)]
+                    plan.process_tracks(tracks[:1])
+                    t0 = time.perf_counter()
+                    plan.process_tracks(tracks)
+                    dt = time.perf_counter() - t0
+                    out["e2e"] = {"upx_process_tracks": {"ms": round(dt * 1e3, 1), "tracks": TRACKS_PER_GPU,
+                                                         "Msamples_per_s": round(nominal * TRACKS_PER_GPU / dt / 1e6, 1)},
+                                  "note": "pageable host buffers, fresh output arrays; uploads, kernels and downloads "
+                                          "of consecutive tracks overlap; PCIe-inclusive (never `value`)"}
+                    del tracks
+                else:
+                    out["e2e"] = e2e_rates(ux, plan, bands, sr, nominal)
+            except Exception as exc:   # a side measurement must not take the bench line down
+                out["e2e"] = {"error": repr(exc)}
+        else:
+            out["e2e"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(sr, max_stft)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -52,8 +52,9 @@ const char* upx_last_error(void);
 int upx_device_count(int* count);
 
 /* 1 if (block_size, hop) is covered by the gfx950 kernels, else 0: power-of-two sizes 64..65536, any hop in
-   [1, N] with at most 64 frames overlapping one sample.  hop = N/2, N/4, N/8 with N in 256..8192 takes the fused
-   streaming kernel, everything else the unfused pipeline. */
+   [1, N] with at most 64 frames overlapping one sample.  hop = N/2, N/4, N/8: band-limited bands (pass band below
+   bin N/32; what the reference's planner gives every large STFT) take the two-kernel band-limited path at any size,
+   other bands with N in 256..8192 the fused streaming kernel; everything else the unfused pipeline. */
 int upx_supported(int32_t block_size, int32_t hop);
 
 /*
@@ -131,12 +132,21 @@ int upx_plan_band_times_ms(upx_plan* plan, float* ms, int n_bands);
 /* Sum over the last n_calls (<= 64) timed upx_process_device calls, with ONE synchronisation: a timed loop can
    run back to back and read its kernel times afterwards. */
 int upx_plan_band_times_sum_ms(upx_plan* plan, float* ms, int n_bands, int n_calls);
+/* The same per call: ms[c * n_bands + b] for the last n_calls (<= 64) timed calls, oldest first (medians). */
+int upx_plan_band_times_calls_ms(upx_plan* plan, float* ms, int n_bands, int n_calls);
+/* Bands on the band-limited two-kernel path (upx_zoom.h): time of the analysis launches and of the synthesis
+   launches (+ the stream seam add), summed over the last n_calls timed calls.  Single-kernel bands report 0 and
+   their whole time.  upx_plan_band_phase_kernel_name: phase 0 = analysis ("" for single-kernel bands), 1 = synthesis
+   or the band's only kernel. */
+int upx_plan_band_phase_times_sum_ms(upx_plan* plan, float* ms_analysis, float* ms_synthesis, int n_bands, int n_calls);
+int upx_plan_band_phase_kernel_name(upx_plan* plan, int band, int phase, char* name, size_t n);
 /* Kernel symbol name / launch geometry of a band (for profiles and DESIGN.md). */
 int upx_plan_band_info(upx_plan* plan, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,
                        int32_t* blocks_per_stream);
 /* Name of the kernel that carries `band`, as rocprofv3 prints it (NUL-terminated, truncated to n bytes):
-   "upx_band_kernel<upx::WideCfg<13, 4>, 2>", "upx_band_kernel<upx::Cfg<10, 4, 16>, 2>", or
-   "unfused<N>" for the multi-kernel path (upx_big_* kernels). */
+   "upx_band_kernel<upx::WideCfg<13, 4>, 2>", "upx_band_kernel<upx::Cfg<10, 4, 16>, 2>",
+   "upx_zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 4>>" for the band-limited two-kernel path (its analysis kernel:
+   upx_plan_band_phase_kernel_name), or "unfused<N>" for the multi-kernel path (upx_big_* kernels). */
 int upx_plan_band_kernel_name(upx_plan* plan, int band, char* name, size_t n);
 
 /*

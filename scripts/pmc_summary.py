@@ -1,22 +1,25 @@
 #!/usr/bin/env python3
-"""Aggregate rocprofv3 --pmc CSVs (gpurun_out/pmc_<tag>/<pass>/**/_counter_collection.csv) per kernel."""
+"""Aggregate rocprofv3 --pmc CSVs (gpurun_out/pmc_<tag>/<pass>/**/_counter_collection.csv) per kernel: every upx_*
+kernel, keyed by the name bench.py reports (template arguments kept, the argument list dropped)."""
 import csv
 import glob
 import json
 import os
+import re
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"pmc_{tag}")
 acc = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(lambda: defaultdict(set))
 for path in glob.glob(os.path.join(root, "*", "**", "*_counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(path)):
         name = row["Kernel_Name"]
-        if "upx_band_kernel" not in name:
+        m = re.search(r"(upx_\w+(<.*>)?)\(", name)
+        if not m:
             continue
-        key = name[name.index("upx_band_kernel"):name.index("(upx")]
+        key = m.group(1)
         acc[key][row["Counter_Name"]] += float(row["Counter_Value"])
         calls[key][row["Counter_Name"]].add(row["Dispatch_Id"])
 out = {}

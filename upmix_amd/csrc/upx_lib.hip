@@ -396,6 +396,7 @@ const ZoomEntry* find_zoom(int log2p, int rg, int k) {
     return it == table.end() ? nullptr : &it->second;
 }
 
+constexpr int kMidEvents = 15;           // up to 8 launch pairs of the band-limited path are timed per phase
 constexpr int kTimingSlots = 64;          // recent upx_process_device calls whose per-band events are kept
 constexpr int kMaxFramesPerSample = 64;   // unfused path: ceil(N / hop) frames overlap one sample
 
@@ -494,6 +495,9 @@ struct BandState {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // current slot of the rings below
     std::vector<hipEvent_t> ring0, ring1;       // kTimingSlots event pairs: one per recent upx_process_device call
     std::vector<char> ring_used;
+    // band-limited path: events between its launches (analysis | synthesis | analysis | ... ), kMidEvents per slot
+    std::vector<hipEvent_t> ring_mid;
+    std::vector<int> ring_mid_n;                // events recorded in each slot (0: phases not split)
 };
 }   // namespace
 
@@ -761,6 +765,11 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         s.ev0 = s.ring0[0];
         s.ev1 = s.ring1[0];
         if (s.group_size == 0) continue;   // carried by its group leader's launch
+        if (s.zoom) {
+            s.ring_mid.assign((size_t)kTimingSlots * kMidEvents, nullptr);
+            s.ring_mid_n.assign(kTimingSlots, 0);
+            for (auto& e : s.ring_mid) HIP_TRY(hipEventCreate(&e));
+        }
         std::vector<float> ws(s.n);
         for (int i = 0; i < s.n; ++i) ws[i] = w_synthesis[off_w + i] / (float)s.n;   // exact: N is a power of two
         HIP_TRY(hipMalloc(&s.d_wa, s.n * sizeof(float)));
@@ -860,6 +869,7 @@ void upx_plan_destroy(upx_plan* p) {
         if (s.d_ramp) (void)hipFree(s.d_ramp);
         for (auto e : s.ring0) if (e) (void)hipEventDestroy(e);
         for (auto e : s.ring1) if (e) (void)hipEventDestroy(e);
+        for (auto e : s.ring_mid) if (e) (void)hipEventDestroy(e);
     }
     for (auto& kv : p->tw) (void)hipFree(kv.second);
     if (p->d_scalar) (void)hipFree(p->d_scalar);
@@ -1028,6 +1038,10 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             const long long streams_per_launch = cap / f;
             const long long slots = (long long)p->n_cu * zoom_resident(s, true);
             if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+            const long long n_pairs_of_launches = (n_streams + streams_per_launch - 1) / streams_per_launch;
+            const bool split = p->timing && 2 * n_pairs_of_launches - 1 <= kMidEvents;
+            int n_mid = 0;
+            hipEvent_t* mid = s.ring_mid.data() + (size_t)slot * kMidEvents;
             int n_launches = 0;
             for (long long s0 = 0; s0 < n_streams; s0 += streams_per_launch, ++n_launches) {
                 const long long ns = n_streams - s0 < streams_per_launch ? n_streams - s0 : streams_per_launch;
@@ -1043,9 +1057,12 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                 if (per_xcd > (pairs + 7) / 8) per_xcd = (pairs + 7) / 8;
                 if (per_xcd < 1) per_xcd = 1;
                 a.pairs_per_wg = (int)per_xcd;
+                if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
                 s.zoom->analysis(a, (int)(8 * per_xcd), p->stream);
+                if (split) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
                 s.zoom->synthesis(a, (int)ns, groups, p->stream);
             }
+            if (p->timing) s.ring_mid_n[slot] = n_mid;
             if (n_streams > 1) {
                 upx::BandArgs sa;
                 std::memset(&sa, 0, sizeof sa);
@@ -1347,6 +1364,70 @@ int upx_plan_band_times_sum_ms(upx_plan* p, float* ms, int n_bands, int n_calls)
         }
         ms[b] = (float)sum;
     }
+    return UPX_OK;
+}
+
+int upx_plan_band_times_calls_ms(upx_plan* p, float* ms, int n_bands, int n_calls) {
+    if (!p || !ms || n_bands != (int)p->bands.size() || n_calls < 1 || n_calls > kTimingSlots)
+        return fail(UPX_ERR_INVALID, "upx_plan_band_times_calls_ms: bad argument (at most %d calls are kept)", kTimingSlots);
+    if ((long long)n_calls > p->timed_calls) return fail(UPX_ERR_INVALID, "only %lld timed calls recorded", p->timed_calls);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int c = 0; c < n_calls; ++c) {
+        const int slot = (int)((p->timed_calls - n_calls + c) % kTimingSlots);
+        for (int b = 0; b < n_bands; ++b) {
+            float t = 0.f;
+            if (p->bands[b].ring_used[slot])
+                HIP_TRY(hipEventElapsedTime(&t, p->bands[b].ring0[slot], p->bands[b].ring1[slot]));
+            ms[(size_t)c * n_bands + b] = t;
+        }
+    }
+    return UPX_OK;
+}
+
+int upx_plan_band_phase_times_sum_ms(upx_plan* p, float* ms_analysis, float* ms_synthesis, int n_bands, int n_calls) {
+    if (!p || !ms_analysis || !ms_synthesis || n_bands != (int)p->bands.size() || n_calls < 1 || n_calls > kTimingSlots)
+        return fail(UPX_ERR_INVALID, "upx_plan_band_phase_times_sum_ms: bad argument");
+    if ((long long)n_calls > p->timed_calls) return fail(UPX_ERR_INVALID, "only %lld timed calls recorded", p->timed_calls);
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int b = 0; b < n_bands; ++b) {
+        const BandState& s = p->bands[b];
+        double sa = 0.0, ss = 0.0;
+        for (long long c = p->timed_calls - n_calls; c < p->timed_calls; ++c) {
+            const int slot = (int)(c % kTimingSlots);
+            if (!s.ring_used[slot]) continue;
+            const int n_mid = s.ring_mid_n.empty() ? 0 : s.ring_mid_n[slot];
+            if (n_mid == 0) {   // one kernel (or unsplit): everything counts as the band's single phase
+                float t = 0.f;
+                HIP_TRY(hipEventElapsedTime(&t, s.ring0[slot], s.ring1[slot]));
+                ss += t;
+                continue;
+            }
+            // ev0 | analysis | mid0 | synthesis | mid1 | analysis | mid2 | ... | synthesis (+ seam add) | ev1
+            const hipEvent_t* mid = s.ring_mid.data() + (size_t)slot * kMidEvents;
+            hipEvent_t prev = s.ring0[slot];
+            for (int i = 0; i <= n_mid; ++i) {
+                const hipEvent_t next = i < n_mid ? mid[i] : s.ring1[slot];
+                float t = 0.f;
+                HIP_TRY(hipEventElapsedTime(&t, prev, next));
+                if (i % 2 == 0) sa += t;
+                else ss += t;
+                prev = next;
+            }
+        }
+        ms_analysis[b] = (float)sa;
+        ms_synthesis[b] = (float)ss;
+    }
+    return UPX_OK;
+}
+
+int upx_plan_band_phase_kernel_name(upx_plan* p, int band, int phase, char* name, size_t n) {
+    if (!p || !name || n == 0 || band < 0 || band >= (int)p->bands.size() || phase < 0 || phase > 1)
+        return fail(UPX_ERR_INVALID, "upx_plan_band_phase_kernel_name: bad argument");
+    const BandState& s = p->bands[p->bands[band].group_leader];
+    if (s.zoom) std::snprintf(name, n, "%s", phase == 0 ? s.zoom->name_analysis : s.zoom->name_synthesis);
+    else if (phase == 0) name[0] = 0;   // single-kernel bands have no separate analysis phase
+    else if (s.kern) std::snprintf(name, n, "%s", s.kern->name);
+    else std::snprintf(name, n, "unfused<%d>", s.n);
     return UPX_OK;
 }
 

@@ -147,6 +147,25 @@ class DevicePlan:
         _lib.check(self._lib.upx_plan_band_times_sum_ms(self.handle, _f32p(ms), self.n_bands, int(n_calls)))
         return ms
 
+    def band_times_calls_ms(self, n_calls: int) -> np.ndarray:
+        """[n_calls, n_bands] kernel time of each of the last n_calls (<= 64) timed calls; one sync."""
+        ms = np.zeros((int(n_calls), self.n_bands), dtype=np.float32)
+        _lib.check(self._lib.upx_plan_band_times_calls_ms(self.handle, _f32p(ms), self.n_bands, int(n_calls)))
+        return ms
+
+    def band_phase_times_sum_ms(self, n_calls: int):
+        """(analysis, synthesis) time per band summed over the last n_calls timed calls (two-kernel bands split;
+        single-kernel bands: (0, whole time))."""
+        a = np.zeros(self.n_bands, dtype=np.float32)
+        s = np.zeros(self.n_bands, dtype=np.float32)
+        _lib.check(self._lib.upx_plan_band_phase_times_sum_ms(self.handle, _f32p(a), _f32p(s), self.n_bands, int(n_calls)))
+        return a, s
+
+    def band_phase_kernel_name(self, band: int, phase: int) -> str:
+        buf = C.create_string_buffer(160)
+        _lib.check(self._lib.upx_plan_band_phase_kernel_name(self.handle, int(band), int(phase), buf, len(buf)))
+        return buf.value.decode()
+
     def band_info(self, band: int) -> dict:
         v = [C.c_int32() for _ in range(4)]
         _lib.check(self._lib.upx_plan_band_info(self.handle, int(band), *(C.byref(i) for i in v)))
@@ -155,7 +174,7 @@ class DevicePlan:
 
     def band_kernel_name(self, band: int) -> str:
         """Kernel symbol (as rocprofv3 prints it) of the launch that carries `band`."""
-        buf = C.create_string_buffer(128)
+        buf = C.create_string_buffer(160)
         _lib.check(self._lib.upx_plan_band_kernel_name(self.handle, int(band), buf, len(buf)))
         return buf.value.decode()
 
