@@ -426,6 +426,11 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        # torch (bundled HIP runtime) and libupmix_hip.so (system HIP runtime) share this process: leave without
+        # running the interpreter's teardown, where the two runtimes' exit handlers can collide
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

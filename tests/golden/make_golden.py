@@ -251,6 +251,50 @@ def f6_degenerate():
     np.savez_compressed(os.path.join(HERE, "f6_degenerate.npz"), **out)
 
 
+EDGE_BANDS = {   # tag: (N, f_low, f_high, mode, width_low, width_high)   sr = 48000
+    "swapped_rc": (1024, 3000.0, 300.0, "raised_cosine", 75.0, 750.0),       # f_low > f_high: bins swap (:342-343, :290-291)
+    "swapped_hz": (1024, 3000.0, 300.0, "hard_zero", 50.0, 50.0),
+    "above_nyquist_rc": (1024, 1920.0, 30000.0, "raised_cosine", 480.0, 7500.0),   # bin_high clamps (:293), no fade-out
+    "above_nyquist_hz": (1024, 1920.0, 30000.0, "hard_zero", 50.0, 50.0),
+    "both_above_rc": (512, 30000.0, 40000.0, "raised_cosine", 100.0, 100.0),      # bin_low > clamped bin_high: silence
+    "fade_wider_than_band": (2048, 100.0, 200.0, "raised_cosine", 5000.0, 40000.0),  # fades clipped at 0 and n_bins
+    "zero_width": (1024, 300.0, 3000.0, "raised_cosine", 0.0, 0.0),
+}
+
+
+def f8_edges():
+    """Band-edge corner cases of _band_limit and non-finite / out-of-range samples (edge cases)."""
+    out, meta = {}, {}
+    x = synth(5000, 80)
+    out["x"] = x
+    for tag, (n, lo, hi, mode, wl, wh) in EDGE_BANDS.items():
+        bex = ce.MultiBandExtractorAccu(n, 0.75, ce.make_blackman_harris, lo, hi, 48000, mode, wl, wh)
+        out[f"{tag}_gain"] = gain_of(bex)
+        (c, l, r) = bex.process_all_blocks(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64))
+        out[f"{tag}_c"], out[f"{tag}_l"], out[f"{tag}_r"] = c, l, r
+    # non-finite samples: one NaN in L, one +Inf in R, far apart; 2-band plan [1024, 512]
+    y = synth(9000, 81).astype(np.float64)
+    y[2000, 0] = np.nan
+    y[6500, 1] = np.inf
+    ext = build_chain([0, 3000], 0.75, ce.make_blackman_harris, 48000, "raised_cosine", 1024, 32)
+    with np.errstate(all="ignore"):
+        (c, l, r), _ = quiet(ce.extract_center_left_right_multi_band_in_memory, y[:, 0], y[:, 1], 48000, ext)
+    out["nonfinite_x"] = y
+    out["nonfinite_c"], out["nonfinite_l"], out["nonfinite_r"] = c, l, r
+    # float64 samples beyond the float32 range (the reference computes in float64 and casts its result to float32)
+    z = synth(9000, 82).astype(np.float64)
+    z[4000:4003, 0] = [1e39, -2e39, 5e38]
+    ext = build_chain([0, 3000], 0.75, ce.make_blackman_harris, 48000, "raised_cosine", 1024, 32)
+    with np.errstate(all="ignore"):
+        (c, l, r), _ = quiet(ce.extract_center_left_right_multi_band_in_memory, z[:, 0], z[:, 1], 48000, ext)
+    out["huge_x"] = z
+    out["huge_c"], out["huge_l"], out["huge_r"] = c, l, r
+    meta["sizes"] = [int(b.block_size) for b in ext]
+    meta["numpy"] = np.__version__
+    np.savez_compressed(os.path.join(HERE, "f8_edges.npz"), **out)
+    json.dump(meta, open(os.path.join(HERE, "f8_edges.json"), "w"), indent=1)
+
+
 def f7_main():
     """Run main.py:main() itself for each export mode with an in-memory soundfile stub."""
     out = {}
@@ -306,7 +350,10 @@ def f7_main():
 
 
 if __name__ == "__main__":
-    for fn in (f0_plan, f1_windows, f2_gains, f3_frames, f4_oneband, f5_multiband, f6_degenerate, f7_main):
+    only = sys.argv[1:]   # e.g. `make_golden.py f8_edges`: regenerate just that fixture
+    for fn in (f0_plan, f1_windows, f2_gains, f3_frames, f4_oneband, f5_multiband, f6_degenerate, f7_main, f8_edges):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("wrote", fn.__name__)
     for f in sorted(os.listdir(HERE)):

@@ -609,3 +609,126 @@ def test_c4_plan_96k_prefix_vs_oracle(ux, orc):
         close(got, r)
         assert float(np.max(np.abs(got - w))) < 1e-6
     plan.close()
+
+
+def test_c4_share_full_size_on_one_device(ux, orc):
+    """BASELINE configs[3], one GPU's share at full size: 15 min of 96 kHz stereo (86.4 M samples), plan
+    [8192 x4, 2048, 512], as ONE device-resident launch per band (what bench.py --workload c4share times and what
+    each of the 8 ranks runs).  The oracle cannot afford the whole signal: windows at the head, in the interior and at
+    the tail, plus size-independent properties (time shards + seams == single launch, streamed == single launch,
+    silence -> exact zeros)."""
+    sr, total = 96000, 86_400_000
+    edges = [0, 30, 120, 480, 1920, 7680]
+    bands = gpu_chain(ux, edges, sr, 8192, 32)
+    ob = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, sr, max_block_size=8192)
+    assert [b.block_size for b in bands] == [8192, 8192, 8192, 8192, 2048, 512]
+    rng = np.random.default_rng((3, 0))          # SURVEY 8(d): C4 shard g = seed (3, g)
+    x = np.empty((total, 2), np.float32)
+    step = 1 << 23
+    for a in range(0, total, step):              # in pieces: no 86.4 M-sample float64 temporaries
+        n = min(step, total - a)
+        m, sd = rng.standard_normal(n), rng.standard_normal(n)
+        x[a:a + n, 0] = 0.1 * (m + 0.5 * sd)
+        x[a:a + n, 1] = 0.1 * (m - 0.5 * sd)
+    plan = ux.DevicePlan(bands)
+    assert "zoom" in plan.band_kernel_name(0) and plan.band_group(0) == (0, 4)   # the four 8192 bands: one band-limited launch
+    d_in = plan.alloc(total * 8)
+    d_out = [plan.alloc(total * 4) for _ in range(3)]
+    out = [np.empty(total, np.float32) for _ in range(3)]
+    try:
+        plan.h2d(d_in, x)
+        plan.process_device(d_in, total, total, d_out[0], d_out[1], d_out[2], total)
+        for o, d in zip(out, d_out):
+            plan.d2h(o, d)
+        assert all(np.all(np.isfinite(o[::97])) for o in out)
+        # oracle windows: head (with its fade-in), two interior windows on the hop_max grid, the tail
+        n = 60000
+        ref = orc.extract_multi_band(x[:n + 8192, 0].astype(np.float64), x[:n + 8192, 1].astype(np.float64), ob)
+        for got, r in zip(out, ref):
+            close(got[:n], r[:n])
+        for a in (2048 * 9000, 2048 * 33333):
+            seg = x[a:a + 90000].astype(np.float64)
+            ref = orc.extract_multi_band(seg[:, 0], seg[:, 1], ob)
+            for got, r in zip(out, ref):
+                close(got[a + 8192:a + 90000 - 8192], r[8192:90000 - 8192])
+        a = (total // 2048 - 40) * 2048
+        seg = x[a:].astype(np.float64)
+        ref = orc.extract_multi_band(seg[:, 0], seg[:, 1], ob)
+        for got, r in zip(out, ref):
+            close(got[a + 8192:], r[8192:])
+        # streamed through the host entry (2^22-sample chunks, seams added on the device) == single launch
+        streamed = plan.process(x)
+        for u, v in zip(out, streamed):
+            assert rms(u.astype(np.float64) - v) < 1e-8
+            assert float(np.max(np.abs(u - v))) < 1e-6
+        del streamed
+        # silence in -> exact zeros out, at full size, on the device-resident path
+        plan.memset(d_in, 0, total * 8)
+        plan.process_device(d_in, total, total, d_out[0], d_out[1], d_out[2], total)
+        z = np.empty(total, np.float32)
+        for d in d_out:
+            plan.d2h(z, d)
+            assert not z.any()
+    finally:
+        plan.free(d_in)
+        for d in d_out:
+            plan.free(d)
+        plan.close()
+
+
+def test_golden_band_edge_corner_cases_and_nonfinite_samples(ux, orc):
+    """Fixture F8 (generated from the reference): swapped band edges, edges above Nyquist, clipped / zero-width fades;
+    NaN and Inf samples; float64 samples beyond the float32 range."""
+    from test_oracle_golden import EDGE_BANDS
+    z = load_golden("f8_edges.npz")
+    x = z["x"]
+    for tag, (n, lo, hi, mode, wl, wh) in EDGE_BANDS.items():
+        bex = ux.MultiBandExtractorAccu(n, 0.75, ux.make_blackman_harris, lo, hi, 48000, mode, wl, wh)
+        for got, k in zip(bex.process_all_blocks(x[:, 0], x[:, 1]), "clr"):
+            close(got, z[f"{tag}_{k}"])
+        if tag == "both_above_rc":
+            assert not any(o.any() for o in bex.process_all_blocks(x[:, 0], x[:, 1]))   # zero gain: exact silence
+        bex.close()
+    bands = gpu_chain(ux, [0, 3000], 48000, 1024, 32)
+    # NaN / Inf: poisoned exactly where the reference is poisoned (the frames of every band that contain the sample,
+    # all three outputs), equal to the reference elsewhere
+    y = z["nonfinite_x"]
+    with np.errstate(all="ignore"):
+        out = ux.extract_center_left_right_multi_band_in_memory(y[:, 0], y[:, 1], 48000, bands)
+    for got, k in zip(out, "clr"):
+        ref = z[f"nonfinite_{k}"]
+        bad_ref, bad = ~np.isfinite(ref), ~np.isfinite(got)
+        if k == "c":
+            # the centre signals of a frame PAIR come out of one inverse transform (C_a + i C_b), so a poisoned frame
+            # takes its pair partner along: at most one more hop (256 = hop of the 1024 band) on either side
+            grown = bad_ref.copy()
+            for sh in range(1, 257):
+                grown[sh:] |= bad_ref[:-sh]
+                grown[:-sh] |= bad_ref[sh:]
+            assert np.all(bad[bad_ref]) and not np.any(bad & ~grown)
+        else:
+            assert np.array_equal(bad, bad_ref), k
+        ok = ~bad
+        assert rms(got[ok].astype(np.float64) - ref[ok]) <= TOL
+    # Samples beyond the float32 range are outside the boundary's dtype contract (float64 input is cast to float32
+    # once on the host, SURVEY 8(b)): the cast gives +-Inf and the result is non-finite on exactly the frames that
+    # contain those samples, in all three outputs (L and R share one complex transform) - where the reference (float64
+    # transforms, float32 cast at the end) returns values of magnitude 1e36+, overflows itself, or, in the channel
+    # that has no such sample, stays ordinary.  Everything outside those frames equals the reference.
+    h = z["huge_x"]
+    with np.errstate(all="ignore"):
+        out = ux.extract_center_left_right_multi_band_in_memory(h[:, 0], h[:, 1], 48000, bands)
+    touched = np.zeros(len(h), bool)                              # frames of either band that contain a huge sample
+    for n0 in (4000, 4001, 4002):
+        for b in bands:
+            n, hop = b.block_size, b.hop_size
+            j_lo, j_hi = max(0, -(-(n0 - n + 1) // hop)), n0 // hop
+            touched[j_lo * hop:min(len(h), j_hi * hop + n)] = True
+    for got, k in zip(out, "clr"):
+        ref = z[f"huge_{k}"]
+        assert not np.isfinite(got[touched]).any(), k             # never a silently wrong finite number
+        if k != "c":
+            assert np.all(np.isfinite(got[~touched])), k          # (C: plus the pair partners' hop, see above)
+        ok = np.isfinite(got) & ~touched
+        assert ok.sum() > len(h) - 4000
+        assert rms(got[ok].astype(np.float64) - ref[ok]) <= TOL

@@ -152,3 +152,12 @@ def test_no_cpu_fallback_in_product(monkeypatch):
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_gain_vectors_of_band_edge_corner_cases_bit_exact():
+    """plan.band_limit_gain on swapped edges, edges above Nyquist, clipped and zero-width fades (fixture F8)."""
+    from test_oracle_golden import EDGE_BANDS
+    z = load_golden("f8_edges.npz")
+    for tag, (n, lo, hi, mode, wl, wh) in EDGE_BANDS.items():
+        g = ux.band_limit_gain(n, 48000, lo, hi, mode, wl, wh)
+        assert g.dtype == np.float64 and np.array_equal(g, z[f"{tag}_gain"]), tag

@@ -1,0 +1,135 @@
+"""
+upmix_amd.multi_gpu (one WAV over the GPUs of a node, BASELINE configs[3]): every rank reads only its time shard and
+writes only its slice of each output file; the ranks agree on ONE scale through a max all-reduce of two scalars.
+CPU: world_size 2 over gloo with the ORACLE as engine and a gloo all-reduce as the seam (the RCCL seam has the same
+algebra, tests/test_sharding.py), compared byte for byte with the single-process host flow (cli.run --host-export,
+itself pinned to main.py by fixture F7).  GPU (-m gpu): world 1 through the real entry point.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import upmix_oracle as orc
+from upmix_amd import cli, export, multi_gpu, sharding, wav
+
+EDGES = [0.0, 300.0, 3000.0]
+
+
+def make_wav(path, total=41000, seed=31, subtype="PCM_16"):
+    x = orc.synthetic_stereo(total, seed).astype(np.float64)
+    x[1000, 0] = 0.93            # the input peak sits in rank 0's shard, the output peak need not
+    wav.write(path, x, 48000, subtype)
+
+
+def oracle_bands():
+    return orc.plan_bands(EDGES, 0.75, orc.win_blackman_harris, 48000, max_block_size=1024)
+
+
+def oracle_engine(bands, world, dist):
+    """(center, left, right) of a shard with the oracle; the seam all-reduce goes over the process group."""
+    def run(local, shard, geo):
+        import torch
+        planes = [np.zeros(shard.t_out, np.float32) for _ in range(3)]
+        for b in bands:
+            res = orc.band_process(local[:, 0].astype(np.float64), local[:, 1].astype(np.float64), b,
+                                   own_len=shard.own_len, out_len=shard.t_out)
+            for f, r in zip(planes, res):
+                f += r
+        if world > 1:
+            t = torch.from_numpy(sharding.pack_seam(planes, shard, world, geo.spill))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            sharding.apply_seam(planes, shard, t.numpy())
+        return tuple(p[:shard.own_len].copy() for p in planes)
+    return run
+
+
+def _worker(rank, world, port, tmp, mode):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bands = oracle_bands()
+    reads = []
+    real_read_range = wav.read_range
+
+    def spy(path, start, count, meta=None):
+        reads.append((int(start), int(count)))
+        return real_read_range(path, start, count, meta)
+    wav.read_range = spy
+    multi_gpu.run_rank(os.path.join(tmp, "in", "song.wav"), os.path.join(tmp, f"out_{mode}"), mode, bands, 0.75,
+                       "PCM_16", rank, world, dist, engine=oracle_engine(bands, world, dist), log=lambda *_: None)
+    # the rank touched its own shard (+ halo) of the input and nothing else
+    geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
+    shard = geo.plan(41000, world)[rank]
+    assert reads == [(shard.start, shard.t_in)], reads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["stereo_sum", "split", "AB"])
+def test_two_rank_gloo_files_equal_single_process(tmp_path, mode):
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "in"))
+    make_wav(os.path.join(tmp, "in", "song.wav"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, tmp, mode), nprocs=2, join=True)
+    # single process, same engine: the reference flow of main.py on the oracle's planes
+    bands = oracle_bands()
+    wave, sr = wav.read(os.path.join(tmp, "in", "song.wav"))
+    c, l, r = orc.extract_multi_band(wave[:, 0], wave[:, 1], bands)
+    export.scale_to_input_peak(c, l, r, export.input_peak(wave))
+    arrays = export.export_arrays(mode, c, l, r, wave[:, 0], wave[:, 1])
+    names = export.export_file_names("song", mode, bands, 0.75)
+    assert arrays
+    for key, arr in arrays.items():
+        ref_path = os.path.join(tmp, "ref_" + names[key])
+        wav.write(ref_path, arr, sr, "PCM_16")
+        got = open(os.path.join(tmp, f"out_{mode}", names[key]), "rb").read()
+        ref = open(ref_path, "rb").read()
+        assert len(got) == len(ref) and got[:44] == ref[:44]
+        a = np.frombuffer(got[44:], "<i2").astype(np.int32)
+        b = np.frombuffer(ref[44:], "<i2").astype(np.int32)
+        # identical except at the one shard seam, where the float32 association of the overlap-add differs
+        # (a sample may land on the other side of a rounding boundary: at most 1 LSB, on few samples)
+        assert np.max(np.abs(a - b)) <= 1 and np.count_nonzero(a != b) <= 16
+
+
+def test_world_one_without_process_group(tmp_path):
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "in"))
+    make_wav(os.path.join(tmp, "in", "song.wav"), subtype="PCM_24")
+    bands = oracle_bands()
+    written = multi_gpu.run_rank(os.path.join(tmp, "in", "song.wav"), os.path.join(tmp, "out"), "stereo_sum", bands,
+                                 0.75, "PCM_24", 0, 1, None, engine=oracle_engine(bands, 1, None), log=lambda *_: None)
+    wave, sr = wav.read(os.path.join(tmp, "in", "song.wav"))
+    c, l, r = orc.extract_multi_band(wave[:, 0], wave[:, 1], bands)
+    export.scale_to_input_peak(c, l, r, export.input_peak(wave))
+    ref_path = os.path.join(tmp, "ref.wav")
+    wav.write(ref_path, export.export_arrays("stereo_sum", c, l, r)["Sum"], sr, "PCM_24")
+    assert open(written["Sum"], "rb").read() == open(ref_path, "rb").read()
+    assert multi_gpu.run_rank(os.path.join(tmp, "in", "song.wav"), os.path.join(tmp, "out2"), "nonsense", bands, 0.75,
+                              "PCM_16", 0, 1, None, engine=oracle_engine(bands, 1, None), log=lambda *_: None) == {}
+
+
+@pytest.mark.gpu
+def test_multi_gpu_entry_world_one_equals_cli(tmp_path, monkeypatch, capsys):
+    """The product entry with one rank writes the files cli.run --host-export writes (byte for byte)."""
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "in"))
+    make_wav(os.path.join(tmp, "in", "song.wav"), total=300000)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    for mode in ("stereo_sum", "AB"):
+        assert multi_gpu.main(["song.wav", "--export-mode", mode, "--in-dir", os.path.join(tmp, "in"), "--out-dir",
+                               os.path.join(tmp, "out_mg"), "--max-stft", "8192"]) == 0
+        ref = cli.run("song.wav", mode, os.path.join(tmp, "in"), os.path.join(tmp, "out_cli"), max_stft=8192,
+                      host_export=True)
+        for key, path in ref.items():
+            other = os.path.join(tmp, "out_mg", os.path.basename(path))
+            assert open(path, "rb").read() == open(other, "rb").read(), (mode, key)
+    capsys.readouterr()

@@ -180,3 +180,50 @@ def test_f7_main_postprocessing():
     lay = orc.export_layout("stereo_sum", c, l, r)
     names = orc.output_names("eyes", "stereo_sum", bands44, 0.75)
     assert np.array_equal(lay["Sum"], z[f"mono_stereo_sum:{os.path.join('out', names['Sum'])}"])
+
+
+EDGE_BANDS = {   # as tests/golden/make_golden.py: tag -> (N, f_low, f_high, mode, width_low, width_high), sr = 48000
+    "swapped_rc": (1024, 3000.0, 300.0, "raised_cosine", 75.0, 750.0),
+    "swapped_hz": (1024, 3000.0, 300.0, "hard_zero", 50.0, 50.0),
+    "above_nyquist_rc": (1024, 1920.0, 30000.0, "raised_cosine", 480.0, 7500.0),
+    "above_nyquist_hz": (1024, 1920.0, 30000.0, "hard_zero", 50.0, 50.0),
+    "both_above_rc": (512, 30000.0, 40000.0, "raised_cosine", 100.0, 100.0),
+    "fade_wider_than_band": (2048, 100.0, 200.0, "raised_cosine", 5000.0, 40000.0),
+    "zero_width": (1024, 300.0, 3000.0, "raised_cosine", 0.0, 0.0),
+}
+
+
+def test_f8_band_edge_corner_cases():
+    """Swapped edges (center_extraction.py:342-343, :290-291), edges above Nyquist (clamp :293, no fade-out :319),
+    fades clipped at bin 0 / n_bins, zero fade widths: gain vectors and band outputs bit for bit."""
+    z = load_golden("f8_edges.npz")
+    x = z["x"].astype(np.float64)
+    for tag, (n, lo, hi, mode, wl, wh) in EDGE_BANDS.items():
+        band = orc.Band(n, 0.75, lo, hi, 48000, mode, wl, wh)
+        assert np.array_equal(orc.band_gain(band), z[f"{tag}_gain"]), tag
+        for got, k in zip(orc.band_process(x[:, 0], x[:, 1], band), "clr"):
+            assert np.array_equal(got, z[f"{tag}_{k}"]), (tag, k)
+    assert not z["both_above_rc_gain"].any() and not z["both_above_rc_c"].any()
+    assert z["swapped_rc_gain"].any() and z["above_nyquist_rc_gain"][-1] == 1.0
+
+
+def test_f8_nonfinite_and_out_of_range_samples():
+    """A NaN / Inf sample poisons exactly the frames that contain it (all three outputs, every band); float64 samples
+    beyond the float32 range stay finite inside the reference's float64 transforms and overflow only in its final
+    float32 cast.  Same placement, same finite values."""
+    z = load_golden("f8_edges.npz")
+    bands = chain([0, 3000], 48000, 1024, 32)
+    assert [b.block_size for b in bands] == json.load(open(os.path.join(GOLDEN, "f8_edges.json")))["sizes"]
+    for tag in ("nonfinite", "huge"):
+        x = z[f"{tag}_x"]
+        with np.errstate(all="ignore"):
+            out = orc.extract_multi_band(x[:, 0], x[:, 1], bands)
+        for got, k in zip(out, "clr"):
+            ref = z[f"{tag}_{k}"]
+            assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref)), (tag, k)
+            ok = np.isfinite(ref)
+            assert np.array_equal(got[ok], ref[ok]), (tag, k)
+    # the NaN at sample 2000 (band sizes 1024 / 512): every frame that covers it, nothing else
+    bad = ~np.isfinite(z["nonfinite_c"])
+    assert bad[2000] and bad[2000 - 700] and not bad[2000 - 1024] and not bad[2000 + 1024] and bad[6500]
+    assert np.array_equal(bad, ~np.isfinite(z["nonfinite_l"])) and np.array_equal(bad, ~np.isfinite(z["nonfinite_r"]))

@@ -139,19 +139,17 @@ def process_sharded_single_device(plan, stereo: np.ndarray, max_shard: int = 1 <
     return tuple(outs)
 
 
-def process_rank(plan, stereo: np.ndarray, rank: int, world: int, seam: Optional["RcclSeam"] = None):
+def process_local_shard(plan, local: np.ndarray, shard: Shard, geo: ShardGeometry, world: int,
+                        seam: Optional["RcclSeam"] = None):
     """
-    One rank's share of a time-sharded run on its own GPU (one process per GPU, SURVEY 8(e)):
-    upload shard `rank` of `stereo` (+ right halo), run every band, exchange the overlap-add seam over
-    RCCL and return (shard, (center, left, right)) for the samples this rank owns.
-    `stereo` is the whole [T,2] signal (a memory-mapped file is fine: only the shard is touched).
+    One rank's GPU work on the samples it has read: `local` = stereo[shard.start : shard.start + shard.t_in]
+    (own range + right halo).  Upload, every band, the overlap-add seam over RCCL, download of the owned range;
+    returns (center, left, right) float32[shard.own_len].
     """
-    geo = ShardGeometry(plan.block_sizes, plan.hops)
-    shard = geo.plan(stereo.shape[0], world)[rank]
     if world > 1 and seam is None:
         raise ValueError("a multi-rank run needs an RcclSeam")
     spill = geo.spill if world > 1 else 0
-    local = np.ascontiguousarray(stereo[shard.start:shard.start + shard.t_in], dtype=np.float32)
+    local = np.ascontiguousarray(local, dtype=np.float32)
     d_in = plan.alloc(max(shard.t_in, 1) * 8)
     planes = [plan.alloc((shard.own_len + spill) * 4) for _ in range(3)]
     try:
@@ -166,7 +164,20 @@ def process_rank(plan, stereo: np.ndarray, rank: int, world: int, seam: Optional
         plan.free(d_in)
         for d in planes:
             plan.free(d)
-    return shard, tuple(outs)
+    return tuple(outs)
+
+
+def process_rank(plan, stereo: np.ndarray, rank: int, world: int, seam: Optional["RcclSeam"] = None):
+    """
+    One rank's share of a time-sharded run on its own GPU (one process per GPU, SURVEY 8(e)):
+    upload shard `rank` of `stereo` (+ right halo), run every band, exchange the overlap-add seam over
+    RCCL and return (shard, (center, left, right)) for the samples this rank owns.
+    `stereo` is the whole [T,2] signal (a memory-mapped file is fine: only the shard is touched).
+    """
+    geo = ShardGeometry(plan.block_sizes, plan.hops)
+    shard = geo.plan(stereo.shape[0], world)[rank]
+    local = stereo[shard.start:shard.start + shard.t_in]
+    return shard, process_local_shard(plan, local, shard, geo, world, seam)
 
 
 class RcclSeam:

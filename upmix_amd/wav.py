@@ -140,3 +140,110 @@ def write_raw(path: str, payload: np.ndarray, samplerate: int, kind: int, channe
         fh.write(b"data" + struct.pack("<I", len(body)) + body)
         if len(body) & 1:
             fh.write(b"\x00")
+
+
+# ---- ranged access for the multi-GPU driver (each rank touches only its time shard) --------------------------------
+def info(path: str):
+    """-> dict(code, bits, channels, rate, n_frames, data_offset): header only, the payload is not read."""
+    with open(path, "rb") as fh:
+        head = fh.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise ValueError(f"{path}: not a RIFF/WAVE file")
+        fmt, data = None, None
+        pos = 12
+        while True:
+            hdr = fh.read(8)
+            if len(hdr) < 8:
+                break
+            tag, size = hdr[:4], struct.unpack("<I", hdr[4:])[0]
+            if tag == b"fmt ":
+                fmt = fh.read(size)
+                if size & 1:
+                    fh.seek(1, 1)
+            elif tag == b"data":
+                data = (pos + 8, size)
+                break
+            else:
+                fh.seek(size + (size & 1), 1)
+            pos += 8 + size + (size & 1)
+        fh.seek(0, 2)
+        file_size = fh.tell()
+    if fmt is None or data is None:
+        raise ValueError(f"{path}: missing fmt or data chunk")
+    code, channels, rate, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if code == _EXT and len(fmt) >= 26:
+        code = struct.unpack("<H", fmt[24:26])[0]
+    size = min(data[1], file_size - data[0])
+    return {"code": code, "bits": bits, "channels": channels, "rate": int(rate),
+            "n_frames": size // (bits // 8 * channels), "data_offset": data[0]}
+
+
+def _decode(raw: bytes, code: int, bits: int, path: str) -> np.ndarray:
+    if code == _FLOAT and bits == 32:
+        return np.frombuffer(raw, dtype="<f4").astype(np.float64)
+    if code == _FLOAT and bits == 64:
+        return np.frombuffer(raw, dtype="<f8").astype(np.float64)
+    if code == _PCM and bits == 8:
+        return (np.frombuffer(raw, dtype=np.uint8).astype(np.float64) - 128.0) / 128.0
+    if code == _PCM and bits == 16:
+        return np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0
+    if code == _PCM and bits == 24:
+        b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - 0x1000000, v)
+        return v.astype(np.float64) / 8388608.0
+    if code == _PCM and bits == 32:
+        return np.frombuffer(raw, dtype="<i4").astype(np.float64) / 2147483648.0
+    raise ValueError(f"{path}: unsupported WAV encoding (format {code}, {bits} bits)")
+
+
+def read_range(path: str, start: int, count: int, meta=None) -> np.ndarray:
+    """Frames [start, start + count) (clipped to the file) as float64 [n] or [n, channels]; only those bytes are read."""
+    meta = meta or info(path)
+    start = max(0, min(int(start), meta["n_frames"]))
+    count = max(0, min(int(count), meta["n_frames"] - start))
+    block = meta["bits"] // 8 * meta["channels"]
+    with open(path, "rb") as fh:
+        fh.seek(meta["data_offset"] + start * block)
+        raw = fh.read(count * block)
+    x = _decode(raw, meta["code"], meta["bits"], path)
+    return x.reshape(-1, meta["channels"]) if meta["channels"] > 1 else x
+
+
+def encode(data: np.ndarray, subtype: str = "PCM_16"):
+    """-> (format code, bits, little-endian payload bytes) of float data in [-1, 1]: the quantisation of `write`."""
+    x = np.asarray(data).astype(np.float64)
+    if subtype == "FLOAT":
+        return _FLOAT, 32, x.astype("<f4").tobytes()
+    if subtype not in ("PCM_16", "PCM_24", "PCM_32"):
+        raise ValueError(f"unsupported subtype {subtype!r}")
+    bits = int(subtype[4:])
+    full = float(2 ** (bits - 1) - 1)
+    q = np.clip(np.rint(x * full), -full - 1, full).astype(np.int64)
+    if bits == 16:
+        return _PCM, bits, q.astype("<i2").tobytes()
+    if bits == 32:
+        return _PCM, bits, q.astype("<i4").tobytes()
+    u = (q & 0xFFFFFF).astype(np.uint32).reshape(-1)
+    return _PCM, bits, np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=1).astype(np.uint8).tobytes()
+
+
+def create(path: str, n_frames: int, samplerate: int, subtype: str = "PCM_16", channels: int = 2) -> int:
+    """Write the header of a file of n_frames frames and size the file; -> byte offset of the sample data.
+    The payload is filled in afterwards with write_at (any process, any order)."""
+    code, bits, _ = encode(np.zeros(0), subtype)
+    block = channels * bits // 8
+    size = int(n_frames) * block
+    fmt = struct.pack("<HHIIHH", code, channels, int(samplerate), int(samplerate) * block, block, bits)
+    head = (b"RIFF" + struct.pack("<I", 4 + 8 + len(fmt) + 8 + size + (size & 1)) + b"WAVE" +
+            b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", size))
+    with open(path, "wb") as fh:
+        fh.write(head)
+        fh.truncate(len(head) + size + (size & 1))
+    return len(head)
+
+
+def write_at(path: str, byte_offset: int, payload: bytes) -> None:
+    with open(path, "r+b") as fh:
+        fh.seek(byte_offset)
+        fh.write(payload)
