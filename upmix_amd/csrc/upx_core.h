@@ -573,7 +573,9 @@ struct Stream {
 // Loads are placed for latency, not where they are used: gains one phase before the mask, the frame's
 // re-read samples at the top of the phase that ends the previous inverse, the new hop one frame ahead.
 // ---------------------------------------------------------------------------
-template <class C, class Ex>
+// MERGED = false: the launch carries ONE band (a.n_gain == 1, the host guarantees it): the second gain slot's
+// registers and loads disappear, which is what keeps the N = 2048 / 4096 kernels free of spills.
+template <class C, class Ex, bool MERGED = true>
 UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     using SC = typename C::Sub;     // the FFT that goes through LDS: the frame itself, or a wide stream's sub-FFT
     using S = Stream<SC>;
@@ -866,7 +868,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const UPX_GLOBAL float* gain = opaque(a.gain);
         cf nyq_y = mk(0.f, 0.f);
         float nyq_c = 0.f;
-        const int n_gain = a.n_gain, gstride = a.gain_stride;
+        const int n_gain = MERGED ? a.n_gain : 1, gstride = a.gain_stride;
         if (mir.first) {
             // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
             const cf z = th.x[H];
@@ -907,9 +909,11 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             // bands overlapping in one bin) are rare and take that path.
             // plain: bin lane + s LANES.  wide: the table is stored in the kernel's bin order (gain_bin)
             add_band(th.g0[s]);
-            if (n_gain > 1) {
-                add_band(th.g1[s]);
-                for (int q = 2; q < n_gain; ++q) add_band(gat(gain + q * gstride, (unsigned)lane, s * LANES));
+            if constexpr (MERGED) {
+                if (n_gain > 1) {
+                    add_band(th.g1[s]);
+                    for (int q = 2; q < n_gain; ++q) add_band(gat(gain + q * gstride, (unsigned)lane, s * LANES));
+                }
             }
             // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
             th.x[s] = swap_add_i(ls, rs);
@@ -953,13 +957,15 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
         for (int s = 0; s < H; ++s) th.g0[s] = gat(gain, (unsigned)(tid % LANES), s * LANES);
         th.gn[0] = gain[N / 2];
-        th.gn[1] = a.n_gain > 1 ? gain[a.gain_stride + N / 2] : 0.f;
-        // (always written: a value kept from the previous frame would be live through the whole loop)
+        if constexpr (MERGED) {
+            th.gn[1] = a.n_gain > 1 ? gain[a.gain_stride + N / 2] : 0.f;
+            // (always written: a value kept from the previous frame would be live through the whole loop)
 #pragma unroll
-        for (int s = 0; s < H; ++s) th.g1[s] = 0.f;
-        if (a.n_gain > 1) {
+            for (int s = 0; s < H; ++s) th.g1[s] = 0.f;
+            if (a.n_gain > 1) {
 #pragma unroll
-            for (int s = 0; s < H; ++s) th.g1[s] = gat(gain + a.gain_stride, (unsigned)(tid % LANES), s * LANES);
+                for (int s = 0; s < H; ++s) th.g1[s] = gat(gain + a.gain_stride, (unsigned)(tid % LANES), s * LANES);
+            }
         }
         S::template read_compute<LAST>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
     };

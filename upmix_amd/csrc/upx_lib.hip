@@ -103,11 +103,13 @@ struct DevExec {
 };
 
 // WPE = waves per SIMD the register allocator must leave room for (2 -> 256 VGPRs, 3 -> 168).
-template <class C, int WPE>
+// MERGED = false: the launch carries one band (one gain slot per bin): the flavour single bands get.
+template <class C, int WPE, bool MERGED = true>
 __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<C::WAVE_SYNC || C::WIDE, C::P> ex;
-    upx::band_program<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    using Ex = DevExec<C::WAVE_SYNC || C::WIDE, C::P>;
+    Ex ex;
+    upx::band_program<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 
 __global__ void upx_stream_seam_add_kernel(upx::BandArgs a, int n_streams, int tail, int hop) {
@@ -412,14 +414,14 @@ const BigEntry* find_big(int log2n) {
     return it == table.end() ? nullptr : &it->second;
 }
 
-template <class C, int WPE>
+template <class C, int WPE, bool MERGED = true>
 struct Entry {
     static constexpr int kLds = C::LDS_CF * (int)sizeof(upx::cf);
     static void launch(const upx::BandArgs& a, int n_wg, hipStream_t st) {
-        hipLaunchKernelGGL((upx_band_kernel<C, WPE>), dim3(n_wg), dim3(C::WG), kLds, st, a);
+        hipLaunchKernelGGL((upx_band_kernel<C, WPE, MERGED>), dim3(n_wg), dim3(C::WG), kLds, st, a);
     }
     static int prepare() {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_band_kernel<C, WPE>),
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_band_kernel<C, WPE, MERGED>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     }
     static void fill(upx::cf* tw) { upx::fill_tables<C>(tw, turn_trig); }
@@ -449,6 +451,16 @@ const KernelEntry* find_kernel(int log2n, int k, int variant) {
     t[std::make_tuple(L, K, 0)] = Entry<upx::WideCfg<L, K>, 2>::get("upx_band_kernel<upx::WideCfg<" #L ", " #K ">, 2>");
         UPX_REG_SMALL(2, 16, 2, 0) UPX_REG_SMALL(4, 16, 2, 0) UPX_REG_SMALL(8, 16, 2, 0)
         UPX_REG_WIDE(12, 2) UPX_REG_WIDE(12, 4) UPX_REG_WIDE(12, 8) UPX_REG_WIDE(13, 2) UPX_REG_WIDE(13, 4) UPX_REG_WIDE(13, 8)
+        // variant 10 = variant 0 for launches that carry a single band (no second gain slot: fewer registers, no spills)
+#define UPX_REG1(L, K) \
+    t[std::make_tuple(L, K, 10)] = Entry<upx::Cfg<L, K, 16>, 2, false>::get("upx_band_kernel<upx::Cfg<" #L ", " #K ", 16>, 2, false>");
+#define UPX_REG1_WIDE(L, K) \
+    t[std::make_tuple(L, K, 10)] = Entry<upx::WideCfg<L, K>, 2, false>::get("upx_band_kernel<upx::WideCfg<" #L ", " #K ">, 2, false>");
+        UPX_REG1(8, 2) UPX_REG1(9, 2) UPX_REG1(10, 2) UPX_REG1(11, 2) UPX_REG1(8, 4) UPX_REG1(9, 4) UPX_REG1(10, 4) UPX_REG1(11, 4)
+        UPX_REG1(8, 8) UPX_REG1(9, 8) UPX_REG1(10, 8) UPX_REG1(11, 8)
+        UPX_REG1_WIDE(12, 2) UPX_REG1_WIDE(12, 4) UPX_REG1_WIDE(12, 8) UPX_REG1_WIDE(13, 2) UPX_REG1_WIDE(13, 4) UPX_REG1_WIDE(13, 8)
+#undef UPX_REG1_WIDE
+#undef UPX_REG1
         UPX_REG_SIZES(2, 8, 4, 1) UPX_REG_SIZES(4, 8, 4, 1) UPX_REG_SIZES(8, 8, 4, 1)
         UPX_REG_SIZES(2, 16, 2, 2) UPX_REG_SIZES(4, 16, 2, 2) UPX_REG_SIZES(8, 16, 2, 2)
 #undef UPX_REG_WIDE
@@ -839,6 +851,17 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                 for (int i = 0; i < nb; ++i) table[(size_t)q * nb + i] = natural[(size_t)q * nb + order(i)];
         }
         s.n_gain = slots;
+        if (s.kern && slots == 1 && s.log2n != 12 && default_variant() == 0 && !std::getenv("UPX_NO_SINGLE_FLAVOUR")) {
+            // one gain slot per bin: the flavour without the second slot's registers (same twiddle / gain layout).
+            // Measured (MI355X, C4 plan): N = 2048 1.52 -> 1.43 ms (its ten spills are gone), N = 512 1.43 -> 1.39;
+            // N = 4096 loses 3 % (its few spills sit on the signal-edge path only), so it keeps the general flavour.
+            const KernelEntry* one = find_kernel(s.log2n, s.n / s.hop, 10);
+            if (one && one->layout == s.kern->layout) {
+                if (int e = one->prepare())
+                    return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
+                s.kern = one;
+            }
+        }
         HIP_TRY(hipMalloc(&s.d_gain, table.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(s.d_gain, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
     }
