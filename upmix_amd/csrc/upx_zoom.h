@@ -89,10 +89,16 @@ struct ZoomCfg {
     static constexpr int LDS_A_CF = RG_ * BUF + TW_CF;     // analysis: sub-FFT buffers, twiddles
     static constexpr int LDS_S_CF = LDS_A_CF + P;          // synthesis: + the staging row of the next spectrum
     static constexpr int LDS_CF = LDS_S_CF;
-    // Waves per SIMD the 160 KB of LDS admit (at most 4: both kernels are written for 128 VGPRs); the register
-    // allocator is given exactly that many (fewer waves -> more registers, never the other way round).
+    // Waves per SIMD the 160 KB of LDS admit (at most 4); the register allocator is given exactly that many
+    // (fewer waves -> more registers, never the other way round).
     static constexpr int waves_by_lds(int lds_cf) { return (160 * 1024 / (lds_cf * 8)) * (WG / 64) / 4; }
-    static constexpr int WPE_A = waves_by_lds(LDS_A_CF) >= 4 ? 4 : (waves_by_lds(LDS_A_CF) < 1 ? 1 : waves_by_lds(LDS_A_CF));
+    // The analysis requests a unit's input one unit ahead when its workgroup is small enough for three of them per
+    // CU at 168 VGPRs (the 16 + 16 prefetched slots live next to the working set).  Workgroups of 8 or 16 waves
+    // (RG = 16 at P >= 512) would drop to ONE per CU that way: they stay at 128 VGPRs and load at the top of the unit.
+    static constexpr bool PREFETCH_A = WG <= 256;
+    static constexpr int WPE_A_MAX = PREFETCH_A ? 3 : 4;
+    static constexpr int WPE_A = waves_by_lds(LDS_A_CF) >= WPE_A_MAX ? WPE_A_MAX
+                                                                      : (waves_by_lds(LDS_A_CF) < 1 ? 1 : waves_by_lds(LDS_A_CF));
     static constexpr int WPE_S = waves_by_lds(LDS_S_CF) >= 4 ? 4 : (waves_by_lds(LDS_S_CF) < 1 ? 1 : waves_by_lds(LDS_S_CF));
     static constexpr int BPT = (P / 2 + WG - 1) / WG;   // bins per thread in the mask phase
     static_assert(RG_ == 4 || RG_ == 8 || RG_ == 16, "residues per workgroup");
@@ -143,6 +149,27 @@ UPX_HD void zoom_ramp_mul(const UPX_GLOBAL cf* seeds, int r, int sl, cf* x, V v)
     put(7, cmul(r6, q1));
 }
 
+// the same from seeds already in registers: sd[0] = b0, sd[1..4] = q, q^2, q^4, q^8 W_N^(-r P)
+template <class V>
+UPX_HD void zoom_ramp_mul_seeds(const cf* sd, cf* x, V v) {
+    const cf b0 = sd[0], q1 = sd[1], q2 = sd[2], q4 = sd[3], q8 = sd[4];
+    auto put = [&](int s, cf rs) {
+        x[s] = cmul(v(s), rs);
+        x[s + 8] = cmul(v(s + 8), cmul(rs, q8));
+    };
+    put(0, b0);
+    put(1, cmul(b0, q1));
+    const cf r2 = cmul(b0, q2);
+    put(2, r2);
+    put(3, cmul(r2, q1));
+    const cf r4 = cmul(b0, q4);
+    put(4, r4);
+    put(5, cmul(r4, q1));
+    const cf r6 = cmul(r4, q2);
+    put(6, r6);
+    put(7, cmul(r6, q1));
+}
+
 // EAGER: all LDS reads of a radix-16 pass (inputs and twiddles, 62 registers) issued before the first multiply
 template <class Z, int PI, bool EAGER, class Ex>
 UPX_HD void zoom_mid_passes(Ex& ex, cf* lds_all, const cf* tw) {
@@ -159,10 +186,14 @@ UPX_HD void zoom_mid_passes(Ex& ex, cf* lds_all, const cf* tw) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Analysis: one workgroup walks `pairs_per_wg` consecutive frame pairs.
-// Per frame:  for each residue group  { load + window + pass 0 (coalesced), scatter | B | passes 1.. (wave-local),
-//             ramp -> own LDS cells | B | sum over the group's residues into registers | B }
-//             then L/R split, gains, mask -> global.
+// Analysis.  A *unit* = (frame, residue group): RG sub-FFTs of one frame.  Per unit:
+//   registers of the previous unit's prefetch x window -> pass 0 (coalesced), scatter; the unit's small loads (ramp
+//   seeds, gains) and THEN the next unit's input + window are requested | B | passes 1.. (wave-local), ramp -> own
+//   LDS cells | B | sum over the group's residues into registers | B |; after a frame's last group: L/R split,
+//   gains, mask -> global.
+// Vector memory loads return in the order they were issued, so a load that is needed soon must never be queued
+// behind one that may miss to HBM: every load of a unit is issued at ONE point, the short ones first, and the long
+// ones (the next unit's 16 + 16 slots) are only waited for a whole unit later.
 // ---------------------------------------------------------------------------------------------------------------
 template <class Z, class Ex>
 UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg_index) {
@@ -172,7 +203,7 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
     using Thread = ThreadT<16>;
     constexpr int P = Z::P, SL = Z::SL, RG = Z::RG, BUF = Z::BUF, LAST = PS::n - 1, BPT = Z::BPT;
     cf* const tw = lds_all + RG * BUF;
-    const int D = a.d, N = a.n;
+    const int D = a.d;
     const int n_groups = D / RG;
 
     ex.each([&](int tid, Thread&) {
@@ -182,46 +213,116 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
     ex.wg_barrier();
 
     // Which pairs this workgroup transforms.  Blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
-    // one and its 4 MB L2), frames overlap K-fold, and a resident workgroup holds one frame's worth of input lines in
-    // that L2: XCD x takes the x-th eighth of the launch's pairs and its workgroups walk it side by side (pair l,
-    // l + n_l, l + 2 n_l, ... for its l-th workgroup), so the XCD's workgroups read neighbouring frames at the same
-    // time: every input line is fetched from HBM once per XCD and the K-1 other reads are L2 hits.  (A speed choice
-    // only: any placement computes the same pairs.)
+    // one and its 4 MB L2) and frames overlap K-fold: XCD x takes the x-th eighth of the launch's pairs and its
+    // workgroups walk it side by side (pair l, l + n_l, l + 2 n_l, ... for its l-th workgroup), so the XCD's
+    // workgroups read neighbouring frames at the same time: an input line is fetched from HBM once per XCD and the
+    // K-1 other reads are L2 hits.  (A speed choice only: any placement computes the same pairs.)
     const int n_pairs = a.pair_end - a.pair0;
     const int per_xcd = (n_pairs + 7) / 8;
     const int xcd = wg_index % 8, l = wg_index / 8, n_l = a.pairs_per_wg;   // pairs_per_wg: workgroups per XCD here
     int q_stop = a.pair0 + (xcd + 1) * per_xcd;
     if (q_stop > a.pair_end) q_stop = a.pair_end;
+
+    struct Unit {
+        int q, half, grp;
+    };
+    auto frame_of = [](const Unit& u) { return 2 * u.q - 1 + u.half; };
+    auto exists = [&](int j) { return j >= a.j_lo && j < a.j_hi; };
+    // the unit after u among the frames that exist (q = q_stop: none)
+    auto advance = [&](Unit u) {
+        for (;;) {
+            if (u.q >= q_stop) return u;
+            if (exists(frame_of(u)) && u.grp + 1 < n_groups) {
+                ++u.grp;
+                return u;
+            }
+            u.grp = -1;   // next frame, group 0 (if the frame exists)
+            if (u.half == 0) u.half = 1;
+            else { u.half = 0; u.q += n_l; }
+            if (u.q >= q_stop) return u;
+            if (exists(frame_of(u))) {
+                u.grp = 0;
+                return u;
+            }
+        }
+    };
+    // input and window of unit u -> th.pre / th.acc_c (coalesced layout: slot s = sample D (sl + SL s) + r of the
+    // frame).  One code path: samples past the signal are read from an in-range address and meet a zero window
+    // (zero extension of center_extraction.py:437-455); a unit past the end re-reads the current one (never used).
+    auto request = [&](int tid, Thread& th, Unit u) {
+        const int rho = tid % RG, sl = tid / RG;
+        const unsigned o = (unsigned)(D * sl + u.grp * RG + rho);
+        const long long stride = (long long)D * SL;                       // samples between slots (uniform)
+        const long long base = (long long)frame_of(u) * a.hop;            // first sample of the frame (uniform)
+        const UPX_GLOBAL cf* in = opaque(a.in);
+        const UPX_GLOBAL float* w_a = opaque(a.w_a);
+        if (base + a.n <= a.t_in) {   // (uniform; both sides issue the same 32 loads)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                th.pre[s] = gat_u(in, base + s * stride, o);
+                th.acc_c[s] = gat_u(w_a, s * stride, o);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const long long left = (long long)a.t_in - (base + s * stride);   // uniform
+                const bool inside = (long long)o < left;
+                th.pre[s] = gat_u(in, inside ? base + s * stride : 0, inside ? o : 0u);
+                const float w = gat_u(w_a, s * stride, o);
+                th.acc_c[s] = inside ? w : 0.f;
+            }
+        }
+    };
+
+    Unit cur{a.pair0 + xcd * per_xcd + l, 0, -1};
+    if (cur.q < q_stop && exists(frame_of(cur))) cur.grp = 0;
+    else cur = advance(cur);
+    if (Z::PREFETCH_A && cur.q < q_stop) ex.each([&, cur](int tid, Thread& th) { request(tid, th, cur); });
+
+    // frames are visited pair by pair; a pair whose frames do not exist still writes its (zero) centre spectrum
     for (int q = a.pair0 + xcd * per_xcd + l; q < q_stop; q += n_l) {
         for (int half = 0; half < 2; ++half) {
             const int j = 2 * q - 1 + half;
-            const bool exists = j >= a.j_lo && j < a.j_hi;
-            if (exists) {
+            const bool ex_j = exists(j);
+            if (ex_j) {
                 for (int grp = 0; grp < n_groups; ++grp) {
-                    // coalesced layout: slot s = sample D (sl + SL s) + r of the frame
-                    ex.each([&, j, grp](int tid, Thread& th) {
+                    const Unit nxt = advance(Unit{q, half, grp});
+                    const bool last_group = grp == n_groups - 1;
+                    ex.each([&, q, half, grp, nxt, last_group](int tid, Thread& th) {
                         const int rho = tid % RG, sl = tid / RG;
-                        const unsigned o = (unsigned)(D * sl + grp * RG + rho);   // slot 0 inside the frame
-                        const long long stride = (long long)D * SL;            // samples between slots (uniform)
-                        const long long base = (long long)j * a.hop;           // first sample of the frame (uniform)
-                        const UPX_GLOBAL cf* in = opaque(a.in);
-                        const UPX_GLOBAL float* w_a = opaque(a.w_a);
-                        if (base + N <= a.t_in) {
+                        if constexpr (Z::PREFETCH_A) {
 #pragma unroll
-                            for (int s = 0; s < 16; ++s)
-                                th.x[s] = scale(gat_u(in, base + s * stride, o), gat_u(w_a, s * stride, o));
-                        } else {
-                            // zero extension past the signal (center_extraction.py:437-455): load an in-range sample,
-                            // zero the window
+                            for (int s = 0; s < 16; ++s) th.x[s] = scale(th.pre[s], th.acc_c[s]);
+                        }
+                        // short loads of this unit first ...
+                        if constexpr (Z::PREFETCH_A) {
+                            const int g = tid / SL, wsl = tid % SL;          // wave-local layout of the later phases
+                            const UPX_GLOBAL cf* seeds = opaque(a.ramp);
+                            const unsigned ro = (unsigned)((grp * RG + g) * (SL + 4));
+                            th.cs[0] = gat(seeds, ro + (unsigned)wsl, 0);
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) {
-                                const long long left = (long long)a.t_in - (base + s * stride);   // uniform
-                                const bool inside = (long long)o < left;
-                                const float w = gat_u(w_a, s * stride, o);
-                                const cf v = gat_u(in, inside ? base + s * stride : 0, inside ? o : 0u);
-                                th.x[s] = scale(v, inside ? w : 0.f);
+                            for (int i = 0; i < 4; ++i) th.cs[1 + i] = gat(seeds, ro, SL + i);
+                        }
+                        if (Z::PREFETCH_A && last_group) {
+                            const UPX_GLOBAL float* gain = opaque(a.gain);
+#pragma unroll
+                            for (int i = 0; i < BPT; ++i) {
+                                const int k = tid + i * Z::WG;
+                                th.g0[i] = k < P / 2 ? gain[k] : 0.f;
+                                th.g1[i] = (k < P / 2 && a.n_gain > 1) ? gain[a.gain_stride + k] : 0.f;
                             }
                         }
+                        UPX_SCHED_FENCE();
+                        if constexpr (Z::PREFETCH_A) {
+                            // ... then the long ones: the next unit (the last unit re-requests itself: no branch, so
+                            // the wait for the short loads above can leave exactly these in flight)
+                            request(tid, th, nxt.q < q_stop ? nxt : Unit{q, half, grp});
+                        } else {
+                            request(tid, th, Unit{q, half, grp});
+#pragma unroll
+                            for (int s = 0; s < 16; ++s) th.x[s] = scale(th.pre[s], th.acc_c[s]);
+                        }
+                        UPX_SCHED_FENCE();
                         S::template pass_compute<0>(th, tw, sl);
                         S::template pass_write<0>(th, lds_all + rho * BUF, sl);
                     });
@@ -230,11 +331,11 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
                     zoom_mid_passes<Z, 1, true>(ex, lds_all, tw);
                     ex.each([&, grp](int tid, Thread& th) {
                         const int g = tid / SL, sl = tid % SL;
-                        // (twiddles read at use: the ramp occupies the registers an eager radix-16 pass would take)
-                        S::template read_compute<LAST, false>(th, lds_all + g * BUF, tw, sl);
+                        S::template read_compute<LAST, Z::PREFETCH_A>(th, lds_all + g * BUF, tw, sl);
                         // slot s holds F_r[k = sl + SL s]: times the ramp, back into the cells this thread has just read
                         cf zv[16];
-                        zoom_ramp_mul<SL>(opaque(a.ramp), grp * RG + g, sl, zv, [&](int s) { return th.x[s]; });
+                        if constexpr (Z::PREFETCH_A) zoom_ramp_mul_seeds(th.cs, zv, [&](int s) { return th.x[s]; });
+                        else zoom_ramp_mul<SL>(opaque(a.ramp), grp * RG + g, sl, zv, [&](int s) { return th.x[s]; });
                         cf* b = lds_all + g * BUF + padp<16>(sl);
 #pragma unroll
                         for (int s = 0; s < 16; ++s) b[s * Z::SP] = zv[s];
@@ -263,7 +364,7 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
                 }
             }
             // L/R split, gains, mask of the bins this thread has summed (no LDS access: no barrier around it)
-            ex.each([&, j, q, half, exists](int tid, Thread& th) {
+            ex.each([&, j, q, half, ex_j](int tid, Thread& th) {
                 const UPX_GLOBAL float* gain = opaque(a.gain);
                 UPX_GLOBAL cf* y = opaque(a.y) + (size_t)(j - a.f0) * P;
                 UPX_GLOBAL cf* yc = opaque(a.yc) + (size_t)(q - (a.f0 + 1) / 2) * P;
@@ -272,12 +373,15 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
                     const int k = tid + i * Z::WG;
                     if (k >= P / 2) break;
                     cf c = mk(0.f, 0.f), ls = c, rs = c;
-                    if (exists) {
+                    if (ex_j) {
                         const cf za = th.part[2 * i], zb = th.part[2 * i + 1];
                         const cf l0 = add_conj(za, zb);      // Z[k] + conj Z[-k]        (x gain/2 = L)
                         const cf r0 = mi_sub_conj(za, zb);   // (Z[k] - conj Z[-k]) / i  (x gain/2 = R)
                         for (int qg = 0; qg < a.n_gain; ++qg) {
-                            const float g2 = gain[qg * a.gain_stride + k];
+                            // slots 0 and 1 were requested with the frame's last unit; more (three or more merged
+                            // bands overlapping in one bin) are rare
+                            const float g2 = (Z::PREFETCH_A && qg < 2) ? (qg == 0 ? th.g0[i] : th.g1[i])
+                                                                       : gain[qg * a.gain_stride + k];
                             if (g2 != 0.f) {
                                 cf l = scale(l0, g2), r = scale(r0, g2), cq, lq, rq;
                                 mask_bin(l, r, cq, lq, rq);
@@ -290,9 +394,9 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
                         else y[P - k] = swap_conj_add_i(ls, rs);
                     }
                     if (half == 0) {
-                        th.cs[i] = c;
+                        th.cs[5 + i] = c;
                     } else {
-                        const cf ca = th.cs[i];
+                        const cf ca = th.cs[5 + i];
                         yc[k] = swap_add_i(ca, c);
                         if (k == 0) yc[P / 2] = mk(0.f, 0.f);
                         else yc[P - k] = swap_conj_add_i(ca, c);
