@@ -446,6 +446,7 @@ struct ThreadT {
     float g0[P / 2];  // first gain slot of the own bins, fetched one phase ahead of the mask
     float g1[P / 2];  // second slot (merged bands)
     float gn[2];      // first two gain slots of the Nyquist bin
+    float g0w[P];     // (upx_zoom.h) synthesis window of the pending last phase, fetched ahead
 };
 
 template <class C>

@@ -535,6 +535,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     // to spare (3 waves per SIMD: 168 VGPRs; or the centre role) they are requested at the top of the transform,
     // BEHIND the ramp seeds (loads return in order), and waited for at its end; otherwise at the top of the last phase.
     constexpr bool EARLY_OLD = Z::WPE_S <= 3 || ROLE == 1;
+    constexpr bool EARLY_WINDOW = Z::WPE_S <= 3;
     for (int t = 0; t < n_tr; ++t) {
         const bool nonzero = spec_of(t) != nullptr;
         ex.each([&, t, nonzero](int tid, Thread& th) {
@@ -552,7 +553,16 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
         ex.wg_barrier();   // B1: the stage row and (previous transform) the sub-FFT buffers have been read by every wave
         ex.each([&, t, nonzero](int tid, Thread& th) {
             put_stage(tid, th);                       // spectrum t+1 (in flight since the previous transform)
-            fetch_spec(tid, th, spec_of(t + 2));
+            if constexpr (EARLY_WINDOW) {
+                // the window of the last phase BEFORE the next long request (loads return in order: queued behind
+                // the spectrum prefetch the window would arrive with it); coalesced layout of that phase
+                const unsigned o = (unsigned)(D * (tid / RG) + grp * RG + tid % RG);
+                const UPX_GLOBAL float* w_s = opaque(a.w_s);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) th.g0w[s] = gat_u(w_s, s * (long long)stride, o);
+                UPX_SCHED_FENCE();
+                fetch_spec(tid, th, spec_of(t + 2));
+            }
             if (nonzero) S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL);
         });
         if (nonzero) {
@@ -583,12 +593,19 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
                 for (int s = 0; s < 16; ++s) th.x[s] = mk(0.f, 0.f);
             }
             UPX_SCHED_FENCE();
-            // (the window only now: sixteen more live registers during the last pass would not fit next to the
-            // overlap-add state; L1 hits)
-            const UPX_GLOBAL float* w_s = opaque(a.w_s);
             float w[16];
+            if constexpr (EARLY_WINDOW) {
 #pragma unroll
-            for (int s = 0; s < 16; ++s) w[s] = gat_u(w_s, s * (long long)stride, o);
+                for (int s = 0; s < 16; ++s) w[s] = th.g0w[s];
+            } else {
+                // (the window only now: sixteen more live registers during the earlier phases do not fit next to
+                // the overlap-add state at 128 VGPRs; and the next long request only behind it)
+                const UPX_GLOBAL float* w_s = opaque(a.w_s);
+#pragma unroll
+                for (int s = 0; s < 16; ++s) w[s] = gat_u(w_s, s * (long long)stride, o);
+                UPX_SCHED_FENCE();
+                fetch_spec(tid, th, spec_of(t + 2));
+            }
             UPX_SCHED_FENCE();
             if (role == 0) {
                 const Hop h = hop_of(tid, m0 + t);
