@@ -13,7 +13,13 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"pmc_{tag}")
 acc = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(lambda: defaultdict(set))
-for path in glob.glob(os.path.join(root, "*", "**", "*_counter_collection.csv"), recursive=True):
+# one CSV per pass: the newest (gpurun merges every run's files into the same directory)
+paths = []
+for pass_dir in sorted(glob.glob(os.path.join(root, "*", ""))):
+    found = glob.glob(os.path.join(pass_dir, "**", "*_counter_collection.csv"), recursive=True)
+    if found:
+        paths.append(max(found, key=os.path.getmtime))
+for path in paths:
     for row in csv.DictReader(open(path)):
         name = row["Kernel_Name"]
         m = re.search(r"(upx_\w+(<.*>)?)\(", name)
