@@ -344,6 +344,9 @@ def f7_main():
         out[f"mono_stereo_sum:{path}"] = data
     out["x"] = x
     out["mono"] = mono
+    # `final_x *= scale_factor` (main.py:95-97) multiplies in float64 under NumPy >= 2 and in float32 under NumPy 1.x
+    # (NEP 50): the fixture pins the behaviour of the NumPy that generated it
+    meta["numpy"] = np.__version__
     np.savez_compressed(os.path.join(HERE, "f7_main.npz"), **out)
     with open(os.path.join(HERE, "f7_main.json"), "w") as fh:
         json.dump(meta, fh, indent=1)

@@ -381,6 +381,34 @@ def test_wav_pipeline_device_codec_and_cli(ux, orc, tmp_path):
     assert np.max(np.abs(c_host - c_wav)) <= 2.0 / 32768
 
 
+def test_device_export_equals_host_export_byte_for_byte(ux, orc, tmp_path):
+    """the CLI's default (codec, peak scale, export layout and quantisation on the GPU) and --host-export
+    (NumPy, pinned to main.py by fixture F7) must write the same files: every export mode x every subtype, from an integer
+    PCM file and from a float file (AB: the original sum L + R is formed in float64 from the decoded samples, as
+    main.py:112-114 does)."""
+    import os
+    from upmix_amd import wav, cli
+    rng = np.random.default_rng(5)
+    os.makedirs(tmp_path / "in")
+    x = np.clip(0.2 * rng.standard_normal((40000, 2)), -0.99, 0.99)
+    wav.write(str(tmp_path / "in" / "a16.wav"), x, 48000, "PCM_16")
+    wav.write(str(tmp_path / "in" / "a24.wav"), x, 48000, "PCM_24")
+    wav.write(str(tmp_path / "in" / "af.wav"), x, 48000, "FLOAT")
+    n = 0
+    for name in ("a16.wav", "a24.wav", "af.wav"):
+        for mode in ("AB", "split", "stereo_sum"):
+            for subtype in ("PCM_16", "PCM_24", "PCM_32", "FLOAT"):
+                kw = dict(max_stft=4096, subtype=subtype)
+                dev = cli.run(name, mode, str(tmp_path / "in"), str(tmp_path / "dev"), **kw)
+                host = cli.run(name, mode, str(tmp_path / "in"), str(tmp_path / "host"), host_export=True, **kw)
+                assert sorted(dev) == sorted(host)
+                for key in dev:
+                    a, b = open(dev[key], "rb").read(), open(host[key], "rb").read()
+                    assert a == b, (name, mode, subtype, key)
+                    n += 1
+    assert n == 3 * (1 + 3 + 1) * 4
+
+
 def test_random_plans_vs_oracle(ux, orc):
     """Seeded random band plans / overlaps / windows / lengths through whichever kernel path they select."""
     rng = np.random.default_rng(2024)
