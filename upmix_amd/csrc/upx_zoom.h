@@ -536,6 +536,10 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     // BEHIND the ramp seeds (loads return in order), and waited for at its end; otherwise at the top of the last phase.
     constexpr bool EARLY_OLD = Z::WPE_S <= 3 || ROLE == 1;
     constexpr bool EARLY_WINDOW = Z::WPE_S <= 3;
+#if !defined(UPX_ZOOM_SYN_EAGER)
+#define UPX_ZOOM_SYN_EAGER 1
+#endif
+    constexpr bool EAGER_PASSES = UPX_ZOOM_SYN_EAGER != 0 && Z::WPE_S <= 3;
     for (int t = 0; t < n_tr; ++t) {
         const bool nonzero = spec_of(t) != nullptr;
         ex.each([&, t, nonzero](int tid, Thread& th) {
@@ -566,10 +570,9 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
             if (nonzero) S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL);
         });
         if (nonzero) {
-#if !defined(UPX_ZOOM_SYN_EAGER)
-#define UPX_ZOOM_SYN_EAGER 0   // the overlap-add state leaves no room for the twiddles of an eager pass
-#endif
-            zoom_mid_passes<Z, 1, UPX_ZOOM_SYN_EAGER != 0>(ex, lds_all, tw);
+            // (eager passes - all LDS reads of a radix-16 pass before its first multiply - only where the LDS footprint
+            // leaves 168 VGPRs: next to the overlap-add state their 30 twiddle registers do not fit 128)
+            zoom_mid_passes<Z, 1, EAGER_PASSES>(ex, lds_all, tw);
         }
         ex.wg_barrier();   // B2: sub-FFT buffers and the stage row complete
         // last pass in the coalesced layout; slot s = sample D (sl + SL s) + r of the frame
@@ -587,7 +590,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
             }
             UPX_SCHED_FENCE();   // issued before anything below
             if (nonzero) {
-                S::template read_compute<LAST, false>(th, lds_all + rho * BUF, tw, sl);
+                S::template read_compute<LAST, EAGER_PASSES>(th, lds_all + rho * BUF, tw, sl);
             } else {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) th.x[s] = mk(0.f, 0.f);
