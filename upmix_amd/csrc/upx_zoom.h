@@ -88,7 +88,10 @@ struct ZoomCfg {
     static constexpr int SP = Sub::SPITCH;
     static constexpr int TW_CF = Sub::TW_CF;
     static constexpr int LDS_A_CF = RG_ * BUF + TW_CF;     // analysis: sub-FFT buffers, twiddles
-    static constexpr int LDS_S_CF = LDS_A_CF + P;          // synthesis: + the staging row of the next spectrum
+    // synthesis: + the staging row of the next spectrum, + (workgroups of up to 4 waves) the ramp seeds of its
+    // residues, so that the only vector-memory loads of a transform are the prefetches (SEEDS_LDS)
+    static constexpr bool SEEDS_LDS = WG <= 256;
+    static constexpr int LDS_S_CF = LDS_A_CF + P + (SEEDS_LDS ? RG_ * (SL + 4) : 0);
     static constexpr int LDS_CF = LDS_S_CF;
     // Waves per SIMD the 160 KB of LDS admit (at most 4); the register allocator is given exactly that many
     // (fewer waves -> more registers, never the other way round).
@@ -149,6 +152,9 @@ UPX_HD void zoom_ramp_mul(const UPX_GLOBAL cf* seeds, int r, int sl, cf* x, V v)
     put(6, r6);
     put(7, cmul(r6, q1));
 }
+
+struct ZoomYes { static constexpr bool value = true; };
+struct ZoomNo { static constexpr bool value = false; };
 
 // the same from seeds already in registers: sd[0] = b0, sd[1..4] = q, q^2, q^4, q^8 W_N^(-r P)
 template <class V>
@@ -425,6 +431,11 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     constexpr int NPT = P / WG;   // spectrum values a thread moves from global memory to the staging row
     cf* const tw = lds_all + RG * BUF;
     cf* const stage = tw + Z::TW_CF;   // the spectrum of the transform about to start, shared by the RG residues
+    cf* const seeds_lds = stage + P;   // SEEDS_LDS: ramp seeds of this workgroup's residues, [RG][SL + 4]
+    // AHEAD_OLD: the old plane values of a transform's hop (HBM misses of bands >= 1) are requested in the LAST phase
+    // of the previous transform, before its stores; possible where nothing short has to be loaded in between
+    // (SEEDS_LDS), because loads return in order
+    constexpr bool AHEAD_OLD = Z::SEEDS_LDS;
     const int D = a.d;
     const int F = a.blocks_per_stream;
     const int sid = a.stream0 + stream_index;
@@ -517,9 +528,14 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     ex.each([&](int tid, Thread& th) {
         const UPX_GLOBAL cf* src = opaque(a.tw);
         for (int i = tid; i < Z::TW_CF; i += WG) tw[i] = src[i];
+        if constexpr (Z::SEEDS_LDS) {
+            const UPX_GLOBAL cf* sd = opaque(a.ramp) + (size_t)grp * RG * (SL + 4);
+            for (int i = tid; i < RG * (SL + 4); i += WG) seeds_lds[i] = sd[i];
+        }
         fetch_spec(tid, th, spec_of(0));
         put_stage(tid, th);
         fetch_spec(tid, th, spec_of(1));
+        if constexpr (AHEAD_OLD) fetch_old(tid, 0, th.pre);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             if (role == 0) th.acc_rl[s] = mk(0.f, 0.f);
@@ -534,23 +550,56 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     // The old plane values of the hop a transform emits are HBM misses.  Where the LDS footprint leaves registers
     // to spare (3 waves per SIMD: 168 VGPRs; or the centre role) they are requested at the top of the transform,
     // BEHIND the ramp seeds (loads return in order), and waited for at its end; otherwise at the top of the last phase.
-    constexpr bool EARLY_OLD = Z::WPE_S <= 3 || ROLE == 1;
+    constexpr bool EARLY_OLD = !AHEAD_OLD && (Z::WPE_S <= 3 || ROLE == 1);
     constexpr bool EARLY_WINDOW = Z::WPE_S <= 3;
 #if !defined(UPX_ZOOM_SYN_EAGER)
 #define UPX_ZOOM_SYN_EAGER 1
 #endif
     constexpr bool EAGER_PASSES = UPX_ZOOM_SYN_EAGER != 0 && Z::WPE_S <= 3;
+    // INTERIOR streams - every frame exists, every hop is emitted and lies inside the planes: all streams but the
+    // first and the last few of a signal - run a loop body whose vector-memory operations are unconditional (same
+    // count on every path).  The backend's s_waitcnt bookkeeping is exact only then: with a branch that issues a
+    // varying number of loads or stores between a load and its use it falls back to vmcnt(0), i.e. it waits for
+    // the youngest prefetch too.
+    const bool interior = m0 >= a.j_lo && m0 + F <= a.j_hi && m0 >= a.m_lo && m0 + F <= a.m_hi &&
+                          (long long)(m0 + F) * a.hop <= a.t_out;
+    auto spec_in = [&](int t) -> const cf* {   // interior: spectrum of transform min(t, last) (re-read past the end: unused)
+        const int tt = t < n_tr ? t : n_tr - 1;
+        return role == 0 ? a.y + (size_t)(m0 + tt - a.f0) * P : a.yc + (size_t)((m0 + 2 * tt + 1) / 2 - (a.f0 + 1) / 2) * P;
+    };
+    auto fetch_old_in = [&](int tid, int t, cf* o8) {   // interior + accumulating: 2 HS unconditional loads
+        const int tt = t < n_tr ? t : n_tr - 1;
+        const unsigned o = (unsigned)(D * (tid / RG) + grp * RG + tid % RG);
+        UPX_GLOBAL float* p0 = role == 0 ? opaque(a.out_l) : opaque(a.out_c);
+        UPX_GLOBAL float* p1 = role == 0 ? opaque(a.out_r) : opaque(a.out_c);
+        const long long b0 = (long long)(role == 0 ? m0 + tt : m0 + 2 * tt) * a.hop;
+        const long long b1 = role == 0 ? b0 : b0 + a.hop;
+#pragma unroll
+        for (int s = 0; s < HS; ++s)
+            o8[s] = mk(gat_u(p0, b0 + s * (long long)stride, o), gat_u(p1, b1 + s * (long long)stride, o));
+    };
+    auto run = [&](auto in_tag, auto acc_tag) {
+    constexpr bool IN = decltype(in_tag)::value;      // interior stream: unconditional loads / stores
+    constexpr bool ACC = decltype(acc_tag)::value;    // (interior only) the band accumulates onto the planes
     for (int t = 0; t < n_tr; ++t) {
-        const bool nonzero = spec_of(t) != nullptr;
+        const bool nonzero = IN || spec_of(t) != nullptr;
         ex.each([&, t, nonzero](int tid, Thread& th) {
             if (nonzero) {
                 const int g = tid / SL, sl = tid % SL;
                 const cf* sp = stage + sl;
-                zoom_ramp_mul<SL>(opaque(a.ramp), grp * RG + g, sl, th.x, [&](int s) { return lds_load(sp + s * SL); });
+                if constexpr (Z::SEEDS_LDS) {
+                    const cf* row = seeds_lds + g * (SL + 4);
+                    const cf sd[5] = {lds_load(row + sl), lds_load(row + SL), lds_load(row + SL + 1), lds_load(row + SL + 2),
+                                      lds_load(row + SL + 3)};
+                    zoom_ramp_mul_seeds(sd, th.x, [&](int s) { return lds_load(sp + s * SL); });
+                } else {
+                    zoom_ramp_mul<SL>(opaque(a.ramp), grp * RG + g, sl, th.x, [&](int s) { return lds_load(sp + s * SL); });
+                }
             }
             if constexpr (EARLY_OLD) {
                 UPX_SCHED_FENCE();
-                fetch_old(tid, t, th.pre);
+                if constexpr (IN && ACC) fetch_old_in(tid, t, th.pre);
+                else if constexpr (!IN) fetch_old(tid, t, th.pre);
             }
             if (nonzero) S::template pass_compute<0>(th, tw, tid % SL);
         });
@@ -565,7 +614,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
 #pragma unroll
                 for (int s = 0; s < 16; ++s) th.g0w[s] = gat_u(w_s, s * (long long)stride, o);
                 UPX_SCHED_FENCE();
-                fetch_spec(tid, th, spec_of(t + 2));
+                fetch_spec(tid, th, IN ? spec_in(t + 2) : spec_of(t + 2));
             }
             if (nonzero) S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL);
         });
@@ -582,11 +631,34 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
             // loads first, stores last: the old plane values of the hop(s) about to be emitted (band sum in list
             // order; HBM misses that the last pass and the overlap-add below cover in part) and the window
             cf old[HS];
-            if constexpr (EARLY_OLD) {
+            if constexpr (EARLY_OLD || AHEAD_OLD) {
 #pragma unroll
-                for (int s = 0; s < HS; ++s) old[s] = th.pre[s];
+                for (int s = 0; s < HS; ++s) old[s] = (!IN || ACC) ? th.pre[s] : mk(0.f, 0.f);
             } else {
-                fetch_old(tid, t, old);
+                if constexpr (IN && ACC) {
+                    fetch_old_in(tid, t, old);
+                } else if constexpr (IN) {
+#pragma unroll
+                    for (int s = 0; s < HS; ++s) old[s] = mk(0.f, 0.f);
+                } else {
+                    fetch_old(tid, t, old);
+                }
+            }
+            if constexpr (AHEAD_OLD) {
+                // fold the old values into the slots about to be emitted, then request the next transform's
+                // (loads first, stores last; same registers)
+#pragma unroll
+                for (int s = 0; s < HS; ++s) {
+                    if (role == 0) {
+                        th.acc_rl[s] = th.acc_rl[s] + mk(old[s].y, old[s].x);   // acc_rl = (Rs, Ls), old = (old_l, old_r)
+                    } else {
+                        th.acc_c[s] += old[s].x;
+                        th.acc_c[s + HS] += old[s].y;
+                    }
+                    old[s] = mk(0.f, 0.f);
+                }
+                if constexpr (IN && ACC) fetch_old_in(tid, t + 1, th.pre);
+                else if constexpr (!IN) fetch_old(tid, t + 1, th.pre);
             }
             UPX_SCHED_FENCE();   // issued before anything below
             if (nonzero) {
@@ -607,11 +679,12 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
 #pragma unroll
                 for (int s = 0; s < 16; ++s) w[s] = gat_u(w_s, s * (long long)stride, o);
                 UPX_SCHED_FENCE();
-                fetch_spec(tid, th, spec_of(t + 2));
+                fetch_spec(tid, th, IN ? spec_in(t + 2) : spec_of(t + 2));
             }
             UPX_SCHED_FENCE();
             if (role == 0) {
-                const Hop h = hop_of(tid, m0 + t);
+                Hop h = hop_of(tid, m0 + t);
+                if constexpr (IN) h.fast = true;
                 UPX_GLOBAL float* out_l = opaque(a.out_l);
                 UPX_GLOBAL float* out_r = opaque(a.out_r);
 #pragma unroll
@@ -628,7 +701,8 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
                 UPX_GLOBAL float* out_c = opaque(a.out_c);
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    const Hop h = hop_of(tid, m0 + 2 * t + half);
+                    Hop h = hop_of(tid, m0 + 2 * t + half);
+                    if constexpr (IN) h.fast = true;
 #pragma unroll
                     for (int s = 0; s < 16; ++s)   // swapped output: c_a = x.y, c_b = x.x
                         th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w[s];
@@ -640,6 +714,10 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
             }
         });
     }
+    };   // run
+    if (interior && a.accumulate) run(ZoomYes{}, ZoomYes{});
+    else if (interior) run(ZoomYes{}, ZoomNo{});
+    else run(ZoomNo{}, ZoomNo{});
     // what is left in the accumulators belongs to the K-1 blocks after this stream
     ex.each([&](int tid, Thread& th) {
         const int rho = tid % RG, sl = tid / RG;
