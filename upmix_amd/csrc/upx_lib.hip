@@ -730,14 +730,15 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     }
     // pass 2: kernel family per group.
     //   band-limited path (upx_zoom.h): hop = N/2, N/4 or N/8, every non-zero gain below bin P/2 for a P = 256, 512 or
-    //     1024 with D = N / P >= 16: the reference's planner makes every band with a large STFT such a band;
+    //     1024 with D = N / P >= 8: the reference's planner makes every band with a large STFT such a band;
     //   fused streaming kernel (upx_core.h): the same hops, N <= 8192, any pass band;
     //   unfused pipeline (upx_big.h): everything else.
     const bool force_unfused = std::getenv("UPX_FORCE_UNFUSED") != nullptr;
     // UPX_ZOOM = smallest decimation D = N / P for which the band-limited path is taken (0: never).  Measured on
-    // the MI355X: from D = 16 on it beats the fused kernel; below, the fused kernel's single launch wins.
+    // the MI355X: from D = 8 on it beats the fused kernel (N = 4096: 0.46 vs 0.54 ms); at D = 4 the fused
+    // kernel's single launch wins.
     const char* zoom_env = std::getenv("UPX_ZOOM");
-    const int zoom_min_d = zoom_env ? std::atoi(zoom_env) : 16;
+    const int zoom_min_d = zoom_env ? std::atoi(zoom_env) : 8;
     for (int b = 0; b < n_bands; ++b) {
         BandState& s = p->bands[b];
         if (s.group_size == 0) continue;
