@@ -53,7 +53,7 @@ int upx_device_count(int* count);
 
 /* 1 if (block_size, hop) is covered by the gfx950 kernels, else 0: power-of-two sizes 64..65536, any hop in
    [1, N] with at most 64 frames overlapping one sample.  hop = N/2, N/4, N/8: band-limited bands (pass band below
-   bin N/32; what the reference's planner gives every large STFT) take the two-kernel band-limited path at any size,
+   bin N/16; what the reference's planner gives every large STFT) take the two-kernel band-limited path at any size,
    other bands with N in 256..8192 the fused streaming kernel; everything else the unfused pipeline. */
 int upx_supported(int32_t block_size, int32_t hop);
 

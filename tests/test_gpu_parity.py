@@ -441,10 +441,10 @@ def test_random_plans_vs_oracle(ux, orc):
 
 
 def test_band_limited_path_random_plans(ux, orc, monkeypatch):
-    """The two-kernel band-limited path (upx_zoom.h) forced onto every band it can carry (UPX_ZOOM=4: decimation
-    D >= 4), on random band-limited plans: STFT 2048 .. 65536, K = 2 / 4 / 8, all windows, both crossover modes,
-    repeated sizes (merged launches), ragged lengths, also streamed in chunks; 1e-5 RMS vs the oracle."""
-    monkeypatch.setenv("UPX_ZOOM", "4")
+    """The two-kernel band-limited path (upx_zoom.h; every band whose pass band allows a decimation D >= 8) on random
+    band-limited plans: STFT 4096 .. 65536, K = 2 / 4 / 8, all windows, both crossover modes, repeated sizes (merged
+    launches), ragged lengths, also streamed in chunks; 1e-5 RMS vs the oracle."""
+    monkeypatch.setenv("UPX_ZOOM", "8")
     rng = np.random.default_rng(77)
     wnames = ["blackman_harris", "hann", "sqrt_hann", "hamming", "blackman"]
     n_zoom = 0
@@ -455,10 +455,10 @@ def test_band_limited_path_random_plans(ux, orc, monkeypatch):
         n_bands = int(rng.integers(1, 5))
         gb, ob, prev, lo = [], [], 0.0, 0.0
         for b in range(n_bands):
-            n = [2048, 4096, 8192, 8192, 16384, 32768, 65536][int(rng.integers(7))]
+            n = [4096, 8192, 8192, 16384, 32768, 65536][int(rng.integers(6))]
             if b and rng.random() < 0.4:
                 n = gb[-1].block_size                               # same size as the previous band: merged launch
-            top = (44100.0 / n) * float(rng.integers(20, 400))      # pass band ends between bin 20 and bin 400
+            top = (44100.0 / n) * float(rng.integers(20, min(400, n // 20)))   # pass band ends between bin 20 and bin 400
             hi = max(lo + 44100.0 / n, top)
             width = 0.25 * hi
             gb.append(ux.MultiBandExtractorAccu(n, overlap, ux.WINDOW_FUNCS[wname], lo, hi, 44100, mode, prev, width))
@@ -529,7 +529,7 @@ def test_kernel_flavours_agree(ux, orc, monkeypatch):
     assert sorted({b.block_size for b in ref_bands}) == [512, 4096, 8192]
     ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ref_bands)
     outs, names = {}, {}
-    for variant, zoom in (("0", "0"), ("2", "0"), ("1", "0"), ("default", None), ("zoom4", "4")):
+    for variant, zoom in (("0", "0"), ("2", "0"), ("1", "0"), ("default", None)):
         monkeypatch.setenv("UPX_KERNEL_VARIANT", variant if variant in "012" else "0")
         if zoom is None:
             monkeypatch.delenv("UPX_ZOOM", raising=False)
@@ -546,11 +546,10 @@ def test_kernel_flavours_agree(ux, orc, monkeypatch):
     assert not any("Wide" in n for n in names["2"]) and any("Cfg<13, 4, 16>" in n for n in names["2"])
     assert any("Cfg<13, 4, 8>" in n for n in names["1"])
     # default: the merged 8192 bands (pass band below bin 128: P = 256, D = 32) take the band-limited path,
-    # the 4096 band (bins up to 426: P = 1024, D = 4) stays fused; UPX_ZOOM=4 moves it over as well
+    # the 4096 band (bins up to 426: P = 1024, D = 4: below the smallest decimation the path is built for) stays fused
     assert any("zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 4>>" in n for n in names["default"])
     assert any("WideCfg<12, 4>" in n for n in names["default"])
-    assert any("ZoomCfg<10, 4, 4>" in n for n in names["zoom4"]) and not any("Wide" in n for n in names["zoom4"])
-    for v in ("2", "1", "default", "zoom4"):
+    for v in ("2", "1", "default"):
         for a, b in zip(outs["0"], outs[v]):
             assert rms(a.astype(np.float64) - b) < 1e-7
 
