@@ -18,9 +18,20 @@
 //                     are P long with hop P/K, so one stream = P/16 lanes walking frames with the overlap-add state
 //                     in registers, exactly like the fused kernel's inverse half (upx_core.h), one per residue.
 // Neither kernel holds what the other needs (no overlap-add state in the analysis, no forward / mask state in
-// the synthesis; Ls/Rs and C streams are separate workgroups), so both fit 128 VGPRs: 4 waves per SIMD where the
-// fused kernel runs 2.  It also lifts the size limit: a frame never has to fit LDS (N = 16 384 .. 65 536 run here
-// without the scratch passes of upx_big.h whenever the band is band-limited, which the reference's planner makes them).
+// the synthesis; Ls/Rs and C streams are separate workgroups), so both run at 3 or 4 waves per SIMD (168 / 128
+// VGPRs: whatever the LDS footprint of the configuration admits, ZoomCfg::WPE_A / WPE_S) where the fused kernel runs 2,
+// with room to request every global access well ahead of its use.  It also lifts the size limit: a frame never has
+// to fit LDS (N = 16 384 .. 65 536 run here without the scratch passes of upx_big.h whenever the band is
+// band-limited, which the reference's planner makes them).
+//
+// Three rules shaped the loops (DESIGN.md 5c has the measurements):
+//   * vector-memory loads return in issue order: a load needed soon is never issued behind one that may miss to HBM
+//     (short loads first, prefetches last, each prefetch waited for a whole unit / transform later);
+//   * the backend's s_waitcnt bookkeeping is exact only when every path between a load and its use issues the same
+//     number of loads and stores: the steady state of the synthesis (interior streams) runs a body without branches
+//     around memory operations, instantiated for accumulate / not;
+//   * LDS stores and paired loads are banked over 32 dwords in groups of 16 contiguous lanes: the residue buffers'
+//     pitch interleaves the residues of such a group (ZoomCfg::BUF).
 //
 // Layouts.  A workgroup holds RG = min(D, 16) residues as RG sub-FFT buffers of P points (Stream<Cfg<log2 P>>):
 //     wave-local  thread t = (g = t / SL, sl = t % SL), SL = P/16: sub-FFT g lives in SL lanes of one wave
@@ -417,7 +428,7 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
 
 // ---------------------------------------------------------------------------------------------------------------
 // Synthesis: one workgroup = RG residue streams of one stream slot (frames m0 .. m0+F-1), role 0 = Ls/Rs, 1 = C.
-// Per transform:  load spectrum, ramp, pass 0 (wave-local, registers only) | B | scatter, passes 1..n-2 | B |
+// Per transform:  staged spectrum x ramp, pass 0 (wave-local, registers only) | B | next spectrum -> stage, scatter, passes 1..n-2 | B |
 //                 last pass (coalesced), window, overlap-add, emit hop.
 // ---------------------------------------------------------------------------------------------------------------
 template <class Z, int ROLE, class Ex>
@@ -546,7 +557,6 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
 
     // Per transform:  staged spectrum x ramp, pass 0 (wave-local, registers) | B1 | next spectrum -> stage, the one
     // after it -> registers, scatter, passes 1..n-2 | B2 | last pass (coalesced), window, overlap-add, emit.
-    // Nothing waits for a load that was issued in the same transform except L1 hits (ramp seeds, window).
     // The old plane values of the hop a transform emits are HBM misses.  Where the LDS footprint leaves registers
     // to spare (3 waves per SIMD: 168 VGPRs; or the centre role) they are requested at the top of the transform,
     // BEHIND the ramp seeds (loads return in order), and waited for at its end; otherwise at the top of the last phase.
