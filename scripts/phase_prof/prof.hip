@@ -62,7 +62,7 @@ __global__ __launch_bounds__(C::WG, 2) void prof_kernel(upx::BandArgs a, unsigne
     ProfExec<C::WAVE_SYNC || C::WIDE, C::P> ex;
     ex.buf = buf; ex.cap = cap;
     ex.rec = blockIdx.x == 0 && (int)(threadIdx.x / 64) == wave;
-    upx::band_program<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    upx::band_program_auto<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 
 static void turn_trig(double frac, double& c, double& s) { c = std::cos(2 * M_PI * frac); s = std::sin(2 * M_PI * frac); }

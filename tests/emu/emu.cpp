@@ -69,8 +69,11 @@ void turn_trig(double frac, double& c, double& s) {
     s = std::sin(a);
 }
 
+long long g_interior_wgs = 0;   // workgroups of the last emu_band() call that took band_program's interior flavour
+
 template <class C>
 int run(upx::BandArgs a) {
+    g_interior_wgs = 0;
     std::vector<upx::cf> tw((size_t)C::TW_CF);
     upx::fill_tables<C>(tw.data(), turn_trig);
     a.tw = tw.data();
@@ -93,12 +96,15 @@ int run(upx::BandArgs a) {
         ex.st.resize(C::WG);
         // poison LDS so that reads of never-written cells are visible
         for (auto& v : lds) v = upx::mk(NAN, NAN);
-        upx::band_program<C>(ex, a, lds.data(), (int)wg);
+        g_interior_wgs += upx::band_interior<C>(a, (int)wg) ? 1 : 0;
+        upx::band_program_auto<C>(ex, a, lds.data(), (int)wg);
     }
     for (long long g = 0; g < n_streams * tail; ++g) upx::stream_seam_add(a, (int)n_streams, tail, C::HOP, g);
     return 0;
 }
 }   // namespace
+
+extern "C" long long emu_last_interior_wgs() { return g_interior_wgs; }
 
 extern "C" int emu_band(int log2n, int k_overlap, int pts, const float* in, long long t_in, float* out_c, float* out_l,
                         float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,

@@ -128,6 +128,31 @@ def test_band_accumulation_order(emu):
         assert rms(g.astype(np.float64) - r) < 1e-7
 
 
+def test_interior_workgroups(emu):
+    """band_program's interior flavour (upx_core.h: branch-free loop body, rotated phases, loads issued early) must run for
+    the workgroups in the middle of a signal and give the oracle's result, overwriting (first band) and accumulating; the
+    first and the last workgroups of a launch must NOT take it (their streams hold frames that do not exist)."""
+    emu.emu_last_interior_wgs.restype = ctypes.c_longlong
+    for n, total, f in ((256, 6000, 4), (1024, 30000, 4), (4096, 90000, 2)):
+        bands = orc.plan_bands([0, 700, 5000], 0.75, orc.win_blackman_harris, 48000, max_block_size=n)
+        bands = [b for b in bands if b.block_size == n][:2]
+        assert len(bands) == 2
+        x = orc.synthetic_stereo(total, n + 1)
+        outs = None
+        for i, b in enumerate(bands):
+            outs = run_emu(emu, b, x, f, outs=outs, accumulate=1 if i else 0)
+            hop = b.hop_size
+            streams = -(-(-(-total // hop) + 1) // (f + (f & 1)))
+            per_wg = max(64 // (n // 16), 1) if PTS[0] != 8 else max(64 // (n // 8), 1)
+            wgs = -(-streams // per_wg)
+            inner = emu.emu_last_interior_wgs()
+            assert 0 < inner <= wgs - 2, (n, inner, wgs)
+        ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), bands)
+        for g, r in zip(outs, ref):
+            assert not np.isnan(g).any()
+            assert rms(g.astype(np.float64) - r) < 1e-7, n
+
+
 def test_short_and_ragged_inputs(emu):
     band = orc.Band(2048, 0.75, 0., 24000., 48000, "raised_cosine", 0., 6000.)
     for total in (1, 511, 512, 513, 1000, 2048, 2049):

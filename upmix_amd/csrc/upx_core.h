@@ -134,6 +134,11 @@ UPX_HD const UPX_GLOBAL T* opaque(const T* p) {
 // constraints of volatile cost more than the pairing - 3.9 ms vs 2.75 ms for C3 - so plain loads stay.)
 UPX_HD cf lds_load(const cf* p) { return *p; }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define UPX_DEVICE_PASS true
+#else
+#define UPX_DEVICE_PASS false
+#endif
 // Stops the instruction scheduler from interleaving independent unrolled
 // iterations across this point (it otherwise trades ~130 extra VGPRs for ILP).
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -333,6 +338,14 @@ struct Cfg {
     static constexpr int LDS_CF = G * PITCH + TW_CF;     // stream buffers + twiddle table
     static constexpr bool WAVE_SYNC = LANES <= 64;       // a stream lives inside one wave: no workgroup barrier needed
     static constexpr bool WIDE = false;
+    // band_program may issue short loads early where registers allow (single-wave streams, hop >= N/4): the analysis
+    // window of a head between the preceding tail's arithmetic and its stores, the mask's gains in front of the prefetch
+    static constexpr bool EARLY_LOADS = LANES <= 64 && K_ <= 4 && P_ == 16;
+    // The exchange in front of the last pass moves values between the 16-lane rows of a wave only when a stream is 2 or
+    // 4 rows wide and the last pass has that radix (N = 512: 16.16.2, N = 1024: 16.16.4): on the device it is done in
+    // registers (Stream::row_exchange) instead of through LDS.  The host emulator keeps the LDS route (same values).
+    static constexpr bool SWAP_LAST = UPX_DEVICE_PASS && P_ == 16 && PS::n == 3 && PS::r[1] == 16 &&
+                                      ((LANES == 64 && PS::r[2] == 4) || (LANES == 32 && PS::r[2] == 2));
     using Sub = Cfg;                                     // the FFT that runs through LDS is the whole frame
     static_assert(K_ == 2 || K_ == 4 || K_ == 8 || K_ == 16, "hop must be N/2, N/4, N/8 or N/16");
     static_assert(P_ % K_ == 0 && P_ >= K_, "hop must be a whole number of register slots");
@@ -379,6 +392,7 @@ struct WideCfg {
     static constexpr int LDS_CF = PITCH + TW_CF;
     static constexpr bool WAVE_SYNC = false;
     static constexpr bool WIDE = true;
+    static constexpr bool EARLY_LOADS = false;
     static_assert(LOG2N_ == 12 || LOG2N_ == 13, "wide streams cover N = 4096 and 8192");
     static_assert(64 % Sub::LANES == 0 && (64 / Sub::LANES) % 2 == 0, "a wave holds whole (g, g^1) pairs of sub-FFTs");
 };
@@ -500,6 +514,48 @@ struct Stream {
 #pragma unroll
         for (int s = 0; s < P; ++s) th.x[s] = lds_load(b + s * C::SPITCH);
     }
+    // Register form of pass_write<n-2> + read_all for streams of ROWS = LANES/16 rows (Cfg::SWAP_LAST): output r = ROWS h + c
+    // of the lane in row a belongs in slot ROWS^2... = (16/ROWS) a + h of the same column in row c - per h a ROWS x ROWS
+    // transpose between the row index and c.  v_permlane32_swap exchanges the upper half of its first operand with the
+    // lower half of the second, v_permlane16_swap the odd rows of the first with the even rows of the second.
+    static UPX_HD void row_exchange(Thread& th) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        constexpr int ROWS = LANES / 16, NH = P / ROWS;
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        cf y[P];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            unsigned v[ROWS][2];
+#pragma unroll
+            for (int c = 0; c < ROWS; ++c) {
+                // (through scalars: __builtin_bit_cast of a vector element `.y` reads element 0 with this hipcc)
+                const float re = th.x[ROWS * h + c].x, im = th.x[ROWS * h + c].y;
+                v[c][0] = __builtin_bit_cast(unsigned, re);
+                v[c][1] = __builtin_bit_cast(unsigned, im);
+            }
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                if constexpr (ROWS == 4) {
+                    u2 a = __builtin_amdgcn_permlane32_swap(v[0][d], v[2][d], false, false);
+                    u2 b = __builtin_amdgcn_permlane32_swap(v[1][d], v[3][d], false, false);
+                    u2 e = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+                    u2 f = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+                    v[0][d] = e.x; v[1][d] = e.y; v[2][d] = f.x; v[3][d] = f.y;
+                } else {
+                    u2 e = __builtin_amdgcn_permlane16_swap(v[0][d], v[1][d], false, false);
+                    v[0][d] = e.x; v[1][d] = e.y;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j)
+                y[NH * j + h] = mk(__builtin_bit_cast(float, v[j][0]), __builtin_bit_cast(float, v[j][1]));
+        }
+#pragma unroll
+        for (int s = 0; s < P; ++s) th.x[s] = y[s];
+#else
+        (void)th;
+#endif
+    }
     // read_all + pass_compute<PI>.  For a radix-P pass all 2P-1 LDS reads (inputs and twiddles) are issued
     // before the first multiply, in the order the butterfly consumes them (its first radix-4 takes inputs 0, 4, 8,
     // 12): left to itself the scheduler splits them into three batches and waits for each to come back in
@@ -536,9 +592,23 @@ struct Stream {
     }
 
     // passes PI..n-2:  [read, transform] | [scatter] |   ('|' = barrier)
-    template <int PI, class Ex>
+    // the last pass after mid_passes<1, SWAP>
+    template <bool SWAP, bool EAGER = true>
+    static UPX_HD void last_compute(Thread& th, const cf* lds, const cf* tw, int lane) {
+        if constexpr (SWAP) pass_compute<PS::n - 1>(th, tw, lane);   // the inputs are in the registers already
+        else read_compute<PS::n - 1, EAGER>(th, lds, tw, lane);
+    }
+    // SWAP (only with C::SWAP_LAST): the exchange in front of the last pass stays in registers; the caller ends the
+    // transform with last_compute<true>
+    template <int PI, bool SWAP = false, class Ex>
     static UPX_HD void mid_passes(Ex& ex, cf* lds_all, const cf* tw) {
-        if constexpr (PI < PS::n - 1) {
+        static_assert(!SWAP || C::SWAP_LAST, "row exchange needs a stream of 2 or 4 rows");
+        if constexpr (SWAP && PI == PS::n - 2) {
+            ex.each([lds_all, tw](int tid, Thread& th) {
+                read_compute<PI>(th, lds_all + (tid / LANES) * C::PITCH, tw, tid % LANES);
+                row_exchange(th);
+            });
+        } else if constexpr (PI < PS::n - 1) {
             // `each2(f, g)`: g scatters into the buffer f has read.  Multi-wave streams need a barrier in
             // between; a stream inside ONE wave does not (LDS operations of a wave execute in order and every
             // scattered value depends on all 16 values read), so its executor runs f and g back to back.
@@ -546,7 +616,7 @@ struct Stream {
             ex.each2(
                 [lds_all, tw](int tid, Thread& th) { read_compute<PI>(th, lds_all + (tid / LANES) * C::PITCH, tw, tid % LANES); },
                 [lds_all](int tid, Thread& th) { pass_write<PI>(th, lds_all + (tid / LANES) * C::PITCH, tid % LANES); });
-            mid_passes<PI + 1>(ex, lds_all, tw);
+            mid_passes<PI + 1, SWAP>(ex, lds_all, tw);
         }
     }
 };
@@ -576,7 +646,13 @@ struct Stream {
 // ---------------------------------------------------------------------------
 // MERGED = false: the launch carries ONE band (a.n_gain == 1, the host guarantees it): the second gain slot's
 // registers and loads disappear, which is what keeps the N = 2048 / 4096 kernels free of spills.
-template <class C, class Ex, bool MERGED = true>
+//
+// IN = true ("interior" workgroup, band_interior() below): every frame of its streams exists and lies inside the
+// signal, every hop is emitted and lies inside the planes, and a.accumulate == ACC.  All but the first and the last few
+// workgroups of a launch are interior.  Their loop body has no branch: every load and store is unconditional, so
+// the backend counts outstanding vector-memory operations exactly (`s_waitcnt vmcnt(n)` leaves the younger prefetches
+// and stores in flight); where paths with different numbers of loads or stores merge it has to wait with vmcnt(0).
+template <class C, class Ex, bool MERGED = true, bool IN = false, bool ACC = false>
 UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     using SC = typename C::Sub;     // the FFT that goes through LDS: the frame itself, or a wide stream's sub-FFT
     using S = Stream<SC>;
@@ -589,6 +665,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     constexpr int SL = SC::LANES;   // lanes per LDS buffer (= LANES unless wide)
     constexpr int BUF = SC::PITCH;  // complex per LDS buffer
     constexpr bool WIDE = C::WIDE;
+    constexpr bool GAINS_EARLY = C::EARLY_LOADS && !MERGED;   // (the merged flavour also holds the second gain slot)
+    constexpr bool SWAP = SC::SWAP_LAST;   // the exchange before the last pass stays in registers (device, 2- or 4-row streams)
 
     // A stream transforms the F frames [m0, m0+F), m0 = m_lo - 1 + stream * F, and nothing else: no halo
     // frames are recomputed.  Frames come in pairs (a, b) = (odd j, j+1) so that one inverse FFT returns the
@@ -598,6 +676,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // blocks of the next stream afterwards (same float32 association as the multi-GPU seam).
     const int F = a.blocks_per_stream;   // even (host guarantees): a stream is a whole number of frame pairs
     const int n_iter = F / 2;
+    int it = 0;   // the frame-pair counter of the main loop (declared here: the pieces below read it; it outlives the
+                  // loop because the host emulator of wide streams runs recorded phases at the next barrier)
 
     cf* const tw = lds_all + C::G * C::PITCH;   // LDS twiddle table, after the stream buffers
     const cf* const bigtw = tw + SC::TW_CF;     // wide: W_N^(k1 n2), row k1 at k1 * BT_ROW
@@ -616,7 +696,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     auto frame_of = [&](int tid, int it, int half, bool& exists) {
         const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
         const int j = m0 + 2 * it + half;
-        exists = j >= a.j_lo && j < a.j_hi && j < m0 + F;
+        exists = IN || (j >= a.j_lo && j < a.j_hi && j < m0 + F);
         return j;
     };
     // Interior frames - all but the last few of a signal - take a branch-free path: one base address per array
@@ -628,7 +708,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const int e = exists ? j * HOP + tid % LANES : 0;
         const UPX_GLOBAL cf* in = opaque(a.in);
         const int last = a.t_in - 1;
-        if (UPX_ALL(e + (P - 1) * LANES <= last)) {
+        if (IN || UPX_ALL(e + (P - 1) * LANES <= last)) {
 #pragma unroll
             for (int s = P - HS; s < P; ++s) th.pre[s - (P - HS)] = gat(in, (unsigned)e, s * LANES);
         } else {
@@ -644,7 +724,19 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // them itself (it cannot tell the planes from the input), and a whole L2 round trip would be exposed.
     struct HeadRegs {
         cf v[P];      // first P-HS used
+        float wa[P];  // analysis window, if have_wa
         bool fast;    // the whole wave loads a frame that lies inside the signal
+        bool have_wa = false;
+    };
+    // The analysis window of the head that follows a tail in the same phase: issued between the tail's arithmetic and
+    // its stores (registers are free there).  Loads return in issue order: behind the stores they would wait for the
+    // stores' acknowledgements before the head can start.
+    auto window_fetch = [&](int tid, HeadRegs& hr) {
+        if constexpr (!C::EARLY_LOADS) return;
+        const UPX_GLOBAL float* w_a = opaque(a.w_a);
+#pragma unroll
+        for (int s = 0; s < P; ++s) hr.wa[s] = gat(w_a, (unsigned)(tid % LANES), s * LANES);
+        hr.have_wa = true;
     };
     auto head_fetch = [&](int tid, int it, int half, HeadRegs& hr) {
         const int lane = tid % LANES;
@@ -653,7 +745,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const int e = exists ? j * HOP + lane : 0;
         const UPX_GLOBAL cf* in = opaque(a.in);
         const int last = a.t_in - 1;   // host guarantees t_in >= 1
-        hr.fast = UPX_ALL(exists && e + (P - 1) * LANES <= last);
+        hr.fast = IN || UPX_ALL(exists && e + (P - 1) * LANES <= last);
         constexpr int NFETCH = P - HS;
         if (hr.fast) {
 #pragma unroll
@@ -671,10 +763,15 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     };
     auto head = [&](int tid, Thread& th, int it, int half, const HeadRegs& hr) {
         const int lane = tid % LANES;
-        const UPX_GLOBAL float* w_a = opaque(a.w_a);
         float wa[P];   // L1 / L2 hits
+        if (hr.have_wa) {
 #pragma unroll
-        for (int s = 0; s < P; ++s) wa[s] = gat(w_a, (unsigned)lane, s * LANES);
+            for (int s = 0; s < P; ++s) wa[s] = hr.wa[s];
+        } else {
+            const UPX_GLOBAL float* w_a = opaque(a.w_a);
+#pragma unroll
+            for (int s = 0; s < P; ++s) wa[s] = gat(w_a, (unsigned)lane, s * LANES);
+        }
         if (hr.fast) {
 #pragma unroll
             for (int s = 0; s < P; ++s) th.x[s] = scale(s < P - HS ? hr.v[s] : th.pre[s < P - HS ? 0 : s - (P - HS)], wa[s]);
@@ -701,6 +798,13 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             S::template pass_compute<0>(th, tw, lane);
         }
         UPX_SCHED_FENCE();   // keep the prefetch behind the loads this frame waits for (vmcnt retires in order)
+        if constexpr (GAINS_EARLY) {
+            // first gain slot of the mask three phases on: in front of the prefetch (an HBM miss), not behind it
+            const UPX_GLOBAL float* gain = opaque(a.gain);
+#pragma unroll
+            for (int s = 0; s < H; ++s) th.g0[s] = gat(gain, (unsigned)lane, s * LANES);
+            th.gn[0] = gain[N / 2];
+        }
         prefetch(tid, th, it + (half == 1 ? 1 : 0), half == 1 ? 0 : 1);
     };
     // last step of an inverse transform: time samples lane + s LANES land in slot s
@@ -712,7 +816,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             for (int r = 0; r < P; ++r) th.x[r] = lds_load(b + wide_sub_of_k1(r) * BUF);
             Dft<16>::run(th.x);
         } else {
-            S::template read_compute<LAST, false>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
+            S::template last_compute<SWAP, false>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
         }
     };
     // first exchange of a forward transform
@@ -736,13 +840,13 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     auto hop_of = [&](int tid, int j) {
         const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
         Hop h;
-        h.emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
+        h.emit = IN || (j >= a.m_lo && j < a.m_hi && j < m0 + F);
         h.e = h.emit ? j * HOP + tid % LANES : 0;
-        h.fast = UPX_ALL(h.emit && h.e + (HS - 1) * LANES <= a.t_out - 1);
+        h.fast = IN || UPX_ALL(h.emit && h.e + (HS - 1) * LANES <= a.t_out - 1);
         return h;
     };
     auto load_old = [&](UPX_GLOBAL float* plane, const Hop& h, float* old) {
-        if (!a.accumulate) {
+        if (!(IN ? ACC : a.accumulate != 0)) {
 #pragma unroll
             for (int s = 0; s < HS; ++s) old[s] = 0.f;
         } else if (h.fast) {
@@ -757,7 +861,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             }
         }
     };
-    auto tail_lr = [&](int tid, Thread& th, int it, int half) {
+    auto no_hook = []() {};
+    auto tail_lr = [&](int tid, Thread& th, int it, int half, auto&& before_stores) {
         const int lane = tid % LANES;
         const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
         const Hop h = hop_of(tid, m0 + 2 * it + half);
@@ -774,6 +879,9 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
         for (int s = 0; s < P; ++s)
             th.acc_rl[s] = th.acc_rl[s] + scale(th.x[s], w[s]);   // swapped output: Ls = Re y = x.y, Rs = Im y = x.x
+        UPX_SCHED_FENCE();
+        before_stores();
+        UPX_SCHED_FENCE();
         if (h.fast) {
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
@@ -794,7 +902,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
         for (int s = 0; s < P; ++s) th.acc_rl[s] = s + HS < P ? th.acc_rl[s + HS] : mk(0.f, 0.f);
     };
-    auto tail_c = [&](int tid, Thread& th, int it) {
+    auto tail_c = [&](int tid, Thread& th, int it, auto&& before_stores) {
         const int lane = tid % LANES;
         const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
         UPX_GLOBAL float* out_c = opaque(a.out_c);
@@ -810,24 +918,33 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
         for (int s = 0; s < P; ++s) w[s] = gat(w_s, (unsigned)lane, s * LANES);
         final_pass(tid, th);
+        float emit_c[2][HS];   // old + new of the two hops; stored after the hook
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
             for (int s = 0; s < P; ++s)   // swapped output: c_a = Re y = x.y ; c_b = Im y = x.x
                 th.acc_c[s] += (half == 0 ? th.x[s].y : th.x[s].x) * w[s];
+#pragma unroll
+            for (int s = 0; s < HS; ++s) emit_c[half][s] = old_c[half][s] + th.acc_c[s];
+#pragma unroll
+            for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
+        }
+        UPX_SCHED_FENCE();
+        before_stores();
+        UPX_SCHED_FENCE();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
             if (h[half].fast) {
 #pragma unroll
-                for (int s = 0; s < HS; ++s) gat(out_c, (unsigned)h[half].e, s * LANES) = old_c[half][s] + th.acc_c[s];
+                for (int s = 0; s < HS; ++s) gat(out_c, (unsigned)h[half].e, s * LANES) = emit_c[half][s];
             } else {
                 const int last = a.t_out - 1;
 #pragma unroll
                 for (int s = 0; s < HS; ++s) {
                     const int n = h[half].e + s * LANES;
-                    if (h[half].emit && n <= last) out_c[n] = old_c[half][s] + th.acc_c[s];
+                    if (h[half].emit && n <= last) out_c[n] = emit_c[half][s];
                 }
             }
-#pragma unroll
-            for (int s = 0; s < P; ++s) th.acc_c[s] = s + HS < P ? th.acc_c[s + HS] : 0.f;
         }
     };
     // Where the mirror bins live.  Own bins k (slots s < H) stay in registers; the partner Z[N-k_s] is read
@@ -952,12 +1069,14 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         S::template pass_compute<0>(th, tw, sl);
     };
     auto scatter0 = [&](int tid, Thread& th) { S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL); };
-    auto mids = [&]() { S::template mid_passes<1>(ex, lds_all, tw); };
+    auto mids = [&]() { S::template mid_passes<1, SWAP>(ex, lds_all, tw); };
     auto zsplit_compute = [&](int tid, Thread& th) {
-        const UPX_GLOBAL float* gain = opaque(a.gain);
+        const UPX_GLOBAL float* gain = opaque(a.gain);   // (slot 0: head())
+        if constexpr (!GAINS_EARLY) {
 #pragma unroll
-        for (int s = 0; s < H; ++s) th.g0[s] = gat(gain, (unsigned)(tid % LANES), s * LANES);
-        th.gn[0] = gain[N / 2];
+            for (int s = 0; s < H; ++s) th.g0[s] = gat(gain, (unsigned)(tid % LANES), s * LANES);
+            th.gn[0] = gain[N / 2];
+        }
         if constexpr (MERGED) {
             th.gn[1] = a.n_gain > 1 ? gain[a.gain_stride + N / 2] : 0.f;
             // (always written: a value kept from the previous frame would be live through the whole loop)
@@ -968,7 +1087,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
                 for (int s = 0; s < H; ++s) th.g1[s] = gat(gain + a.gain_stride, (unsigned)(tid % LANES), s * LANES);
             }
         }
-        S::template read_compute<LAST>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
+        S::template last_compute<SWAP>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
     };
     auto zsplit_write = [&](int tid, Thread& th) {
         cf* b = lds_all + (tid / SL) * BUF + padp<P>(tid % SL);
@@ -1001,7 +1120,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             cf bw[P];
 #pragma unroll
             for (int s = 0; s < P; ++s) bw[s] = lds_load(bt + s * SL);
-            S::template read_compute<LAST>(th, lds_all + g * BUF, tw, sl);
+            S::template last_compute<SWAP>(th, lds_all + g * BUF, tw, sl);
 #pragma unroll
             for (int s = 0; s < P; ++s) b[s * SP] = cmul(th.x[s], bw[s]);
         }
@@ -1041,13 +1160,52 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // and which copy a frame meets would then depend on how the signal is cut into streams.
     // Wide streams: `each` orders one wave only; the cross-wave phases (final_pass reads, head_write writes)
     // touch lane-private cells, so they need barriers only against the wave-local phases around them.
-    int it = 0;   // outlives the loop: the host emulator of wide streams runs recorded phases at the next barrier
+    if constexpr (IN) {
+        // the same phases, rotated so that the body is straight-line code: the centre tail of pair `it` runs with the
+        // head of pair it+1 at the END of trip `it`; the last trip heads a frame of the next stream (inside the signal
+        // by the definition of interior) and nothing uses it.  (`it` by value: an executor may run a phase after ++it)
+        ex.each2(
+            [&, it](int tid, Thread& th) {
+                HeadRegs hr;
+                head_fetch(tid, 0, 0, hr);
+                head(tid, th, 0, 0, hr);
+            },
+            head_write);
+        for (; it < n_iter; ++it) {
+            frame_body(0);
+            ex.each2(
+                [&, it](int tid, Thread& th) {
+                    HeadRegs hr;
+                    head_fetch(tid, it, 1, hr);
+                    tail_lr(tid, th, it, 0, [&]() { window_fetch(tid, hr); });
+                    head(tid, th, it, 1, hr);
+                },
+                head_write);
+            frame_body(1);
+            if constexpr (WIDE) {
+                ex.each([&, it](int tid, Thread& th) { tail_lr(tid, th, it, 1, no_hook); });
+                ex.wg_barrier();
+                ex.each(stage_c);
+            } else {
+                ex.each2([&, it](int tid, Thread& th) { tail_lr(tid, th, it, 1, no_hook); }, stage_c);
+            }
+            inverse_body();
+            ex.each2(
+                [&, it](int tid, Thread& th) {
+                    HeadRegs hr;
+                    head_fetch(tid, it + 1, 0, hr);
+                    tail_c(tid, th, it, [&]() { window_fetch(tid, hr); });
+                    head(tid, th, it + 1, 0, hr);
+                },
+                head_write);
+        }
+    } else
     for (; it <= n_iter; ++it) {
         ex.each2(
             [&](int tid, Thread& th) {
                 HeadRegs hr;
                 if (it < n_iter) head_fetch(tid, it, 0, hr);
-                if (it > 0) tail_c(tid, th, it - 1);
+                if (it > 0) tail_c(tid, th, it - 1, no_hook);
                 if (it < n_iter) head(tid, th, it, 0, hr);
             },
             [&](int tid, Thread& th) {
@@ -1059,17 +1217,17 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             [&](int tid, Thread& th) {
                 HeadRegs hr;
                 head_fetch(tid, it, 1, hr);
-                tail_lr(tid, th, it, 0);
+                tail_lr(tid, th, it, 0, [&]() { window_fetch(tid, hr); });
                 head(tid, th, it, 1, hr);
             },
             head_write);
         frame_body(1);
         if constexpr (WIDE) {
-            ex.each([&](int tid, Thread& th) { tail_lr(tid, th, it, 1); });
+            ex.each([&](int tid, Thread& th) { tail_lr(tid, th, it, 1, no_hook); });
             ex.wg_barrier();   // every wave has read its columns before the centre pair is staged over them
             ex.each(stage_c);
         } else {
-            ex.each2([&](int tid, Thread& th) { tail_lr(tid, th, it, 1); }, stage_c);
+            ex.each2([&](int tid, Thread& th) { tail_lr(tid, th, it, 1, no_hook); }, stage_c);
         }
         inverse_body();
     }
@@ -1086,6 +1244,29 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         }
     });
     if constexpr (WIDE) ex.wg_barrier();
+}
+
+// Workgroup `wg_index` is interior (band_program<.., IN = true>): its streams' frames m0 .. m0+F-1 all exist, are emitted
+// and lie inside the signal and the planes, and so do the two frames after them (the rotated loop heads and prefetches
+// them without using them).
+template <class C>
+UPX_HD bool band_interior(const BandArgs& a, int wg_index) {
+    const long long F = a.blocks_per_stream;
+    const long long first = (long long)a.m_lo - 1 + (long long)wg_index * C::G * F;   // first frame of the first stream
+    const long long end = first + C::G * F;                                           // one past the last stream's frames
+    const long long lo = a.j_lo > a.m_lo ? a.j_lo : a.m_lo;
+    const long long hi = a.j_hi < a.m_hi ? a.j_hi : a.m_hi;
+    return first >= (lo > 0 ? lo : 0) && end <= hi && end * C::HOP <= a.t_out && (end + 1) * C::HOP + C::N <= a.t_in;
+}
+// band_program with the interior flavour where it applies (the choice is uniform over the workgroup)
+template <class C, class Ex, bool MERGED = true>
+UPX_HD void band_program_auto(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
+    if (band_interior<C>(a, wg_index)) {
+        if (a.accumulate) band_program<C, Ex, MERGED, true, true>(ex, a, lds_all, wg_index);
+        else band_program<C, Ex, MERGED, true, false>(ex, a, lds_all, wg_index);
+    } else {
+        band_program<C, Ex, MERGED, false, false>(ex, a, lds_all, wg_index);
+    }
 }
 
 // Adds the tail of stream `sid` onto the first blocks of stream sid+1; one call per (sid, i), i < (K-1) hop.

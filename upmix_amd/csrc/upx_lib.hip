@@ -109,7 +109,7 @@ __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Ex = DevExec<C::WAVE_SYNC || C::WIDE, C::P>;
     Ex ex;
-    upx::band_program<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    upx::band_program_auto<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 
 __global__ void upx_stream_seam_add_kernel(upx::BandArgs a, int n_streams, int tail, int hop) {

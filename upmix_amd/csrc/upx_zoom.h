@@ -189,17 +189,25 @@ UPX_HD void zoom_ramp_mul_seeds(const cf* sd, cf* x, V v) {
 }
 
 // EAGER: all LDS reads of a radix-16 pass (inputs and twiddles, 62 registers) issued before the first multiply
-template <class Z, int PI, bool EAGER, class Ex>
+// SWAP (wave-local layout on both sides, Sub::SWAP_LAST): the exchange before the last pass stays in registers
+// (Stream::row_exchange); the caller ends the transform with S::last_compute<true>
+template <class Z, int PI, bool EAGER, bool SWAP = false, class Ex>
 UPX_HD void zoom_mid_passes(Ex& ex, cf* lds_all, const cf* tw) {
     using S = Stream<typename Z::Sub>;
     using Thread = ThreadT<16>;
-    if constexpr (PI < Z::Sub::PS::n - 1) {
+    static_assert(!SWAP || Z::Sub::SWAP_LAST, "row exchange needs sub-FFTs of 2 or 4 rows");
+    if constexpr (SWAP && PI == Z::Sub::PS::n - 2) {
+        ex.each([lds_all, tw](int tid, Thread& th) {
+            S::template read_compute<PI, EAGER>(th, lds_all + (tid / Z::SL) * Z::BUF, tw, tid % Z::SL);
+            S::row_exchange(th);
+        });
+    } else if constexpr (PI < Z::Sub::PS::n - 1) {
         ex.each2(
             [lds_all, tw](int tid, Thread& th) {
                 S::template read_compute<PI, EAGER>(th, lds_all + (tid / Z::SL) * Z::BUF, tw, tid % Z::SL);
             },
             [lds_all](int tid, Thread& th) { S::template pass_write<PI>(th, lds_all + (tid / Z::SL) * Z::BUF, tid % Z::SL); });
-        zoom_mid_passes<Z, PI + 1, EAGER>(ex, lds_all, tw);
+        zoom_mid_passes<Z, PI + 1, EAGER, SWAP>(ex, lds_all, tw);
     }
 }
 
@@ -346,10 +354,10 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
                     });
                     ex.wg_barrier();
                     // wave-local layout: sub-FFT g
-                    zoom_mid_passes<Z, 1, true>(ex, lds_all, tw);
+                    zoom_mid_passes<Z, 1, true, Z::Sub::SWAP_LAST>(ex, lds_all, tw);
                     ex.each([&, grp](int tid, Thread& th) {
                         const int g = tid / SL, sl = tid % SL;
-                        S::template read_compute<LAST, Z::PREFETCH_A>(th, lds_all + g * BUF, tw, sl);
+                        S::template last_compute<Z::Sub::SWAP_LAST, Z::PREFETCH_A>(th, lds_all + g * BUF, tw, sl);
                         // slot s holds F_r[k = sl + SL s]: times the ramp, back into the cells this thread has just read
                         cf zv[16];
                         if constexpr (Z::PREFETCH_A) zoom_ramp_mul_seeds(th.cs, zv, [&](int s) { return th.x[s]; });
