@@ -3,10 +3,11 @@ order; `B1/B2/B3` = time spent in the workgroup barriers of wide streams; ticks 
 import numpy as np, sys
 def load(p): return np.fromfile(p, dtype=np.uint64).astype(np.int64)
 def wide_labels(n_sub_passes):
-    mids = ["mid_c","mid_w"]*(n_sub_passes-2)
+    mids = ["mid_c+swap"]*(n_sub_passes-2)   # sub-FFT of 512 points: the exchange before its last pass stays in registers
     inv = ["inv0","scat0"]+mids+["sub_last_inv","B2"]
     fb = ["B1","sub_first","scat0"]+mids+["zsplit_c","zsplit_w","mask"]+inv
-    return ["tail_c+head","head_w"]+fb+["tail_lr+head","head_w"]+fb+["tail_lr","B3","stage_c"]+inv
+    # interior workgroups (the recorded one): the loop is rotated, tail_c + head end the trip
+    return fb+["tail_lr+head","head_w"]+fb+["tail_lr","B3","stage_c"]+inv+["tail_c+head","head_w"]
 def plain_labels(n_passes, wave_sync, swap=False):
     """swap: the exchange before the last pass stays in registers (N = 512, 1024): one phase instead of two"""
     def e2(a,b): return [a,b] if wave_sync else [a,a+"|bar",b,b+"|bar"]
@@ -15,7 +16,7 @@ def plain_labels(n_passes, wave_sync, swap=False):
     for i in range(n_passes-2): mids+=(e1("mid_c+swap") if swap else e2("mid_c","mid_w"))
     inv = e2("inv0","scat0")+mids
     fb = mids+e2("zsplit_c","zsplit_w")+e1("mask")+inv
-    return e2("tail_c+head","head_w")+fb+e2("tail_lr+head","head_w")+fb+e2("tail_lr","stage_c")+inv
+    return fb+e2("tail_lr+head","head_w")+fb+e2("tail_lr","stage_c")+inv+e2("tail_c+head","head_w")   # rotated (interior)
 def report(path, labels, pro, iters):
     t=load(path); per=len(labels)
     assert len(t)>=pro+per*iters, (len(t),pro,per,iters)
@@ -36,14 +37,14 @@ def report(path, labels, pro, iters):
 if __name__=="__main__":
   which=sys.argv[1]
   if which=="all":
-      report("gpurun_out/prof/p_13_1_w0.bin", wide_labels(3), 3, 28)
-      report("gpurun_out/prof/p_13_1_w7.bin", wide_labels(3), 3, 28)
-      report("gpurun_out/prof/p_12_1_w0.bin", wide_labels(2), 3, 14)
-      report("gpurun_out/prof/p_10_0_w0.bin", plain_labels(3,True,True), 2, 14)
-      report("gpurun_out/prof/p_8_0_w0.bin", plain_labels(2,True), 2, 14)
-  if which=="13w": report("gpurun_out/prof/p_13_1_w%s.bin"%sys.argv[2], wide_labels(3), 3, 28)
-  if which=="12w": report("gpurun_out/prof/p_12_1_w0.bin", wide_labels(2), 3, 14)
+      report("gpurun_out/prof/p_13_1_w0.bin", wide_labels(3), 5, 28)
+      report("gpurun_out/prof/p_13_1_w7.bin", wide_labels(3), 5, 28)
+      report("gpurun_out/prof/p_12_1_w0.bin", wide_labels(2), 5, 14)
+      report("gpurun_out/prof/p_10_0_w0.bin", plain_labels(3,True,True), 4, 14)
+      report("gpurun_out/prof/p_8_0_w0.bin", plain_labels(2,True), 4, 14)
+  if which=="13w": report("gpurun_out/prof/p_13_1_w%s.bin"%sys.argv[2], wide_labels(3), 5, 28)
+  if which=="12w": report("gpurun_out/prof/p_12_1_w0.bin", wide_labels(2), 5, 14)
   if which=="13p": report("gpurun_out/prof/p_13_0_w0.bin", plain_labels(4,False), 4, 28)
   if which=="12p": report("gpurun_out/prof/p_12_0_w0.bin", plain_labels(3,False), 4, 14)
-  if which=="10p": report("gpurun_out/prof/p_10_0_w0.bin", plain_labels(3,True,True), 2, 14)
-  if which=="8p": report("gpurun_out/prof/p_8_0_w0.bin", plain_labels(2,True), 2, 14)
+  if which=="10p": report("gpurun_out/prof/p_10_0_w0.bin", plain_labels(3,True,True), 4, 14)
+  if which=="8p": report("gpurun_out/prof/p_8_0_w0.bin", plain_labels(2,True), 4, 14)

@@ -61,7 +61,8 @@ __global__ __launch_bounds__(C::WG, 2) void prof_kernel(upx::BandArgs a, unsigne
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ProfExec<C::WAVE_SYNC || C::WIDE, C::P> ex;
     ex.buf = buf; ex.cap = cap;
-    ex.rec = blockIdx.x == 0 && (int)(threadIdx.x / 64) == wave;
+    // a workgroup in the middle of the launch: it runs band_program's interior flavour (rotated loop)
+    ex.rec = blockIdx.x == gridDim.x / 2 && (int)(threadIdx.x / 64) == wave;
     upx::band_program_auto<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 

@@ -187,6 +187,25 @@ UPX_HD const UPX_GLOBAL T& gat(const UPX_GLOBAL T* base, unsigned voff, int c) {
     return gat(const_cast<UPX_GLOBAL T*>(base), voff, c);
 }
 
+// Plane values are read once and written once per band: non-temporal accesses (`nt`) keep them from displacing the
+// input lines that the next three frames read again from L2.
+template <class T>
+UPX_HD T load_nt(const UPX_GLOBAL T& ref) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(&ref);
+#else
+    return ref;
+#endif
+}
+template <class T>
+UPX_HD void store_nt(UPX_GLOBAL T& ref, T v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, &ref);
+#else
+    ref = v;
+#endif
+}
+
 // Element `uniform + voff` of a global array: `uniform` (elements) is the same for every lane and need not be a
 // compile-time constant (it joins the base in SGPRs), `voff` is the lane's own 32-bit element offset:
 // `global_load/store v, v_off, s[base:base+1]` without 64-bit vector arithmetic.
@@ -851,7 +870,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             for (int s = 0; s < HS; ++s) old[s] = 0.f;
         } else if (h.fast) {
 #pragma unroll
-            for (int s = 0; s < HS; ++s) old[s] = gat(plane, (unsigned)h.e, s * LANES);
+            for (int s = 0; s < HS; ++s) old[s] = load_nt(gat(plane, (unsigned)h.e, s * LANES));
         } else {
             const int last = a.t_out - 1;
 #pragma unroll
@@ -885,8 +904,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         if (h.fast) {
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
-                gat(out_l, (unsigned)h.e, s * LANES) = old_l[s] + th.acc_rl[s].y;
-                gat(out_r, (unsigned)h.e, s * LANES) = old_r[s] + th.acc_rl[s].x;
+                store_nt(gat(out_l, (unsigned)h.e, s * LANES), old_l[s] + th.acc_rl[s].y);
+                store_nt(gat(out_r, (unsigned)h.e, s * LANES), old_r[s] + th.acc_rl[s].x);
             }
         } else {
             const int last = a.t_out - 1;
@@ -936,7 +955,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         for (int half = 0; half < 2; ++half) {
             if (h[half].fast) {
 #pragma unroll
-                for (int s = 0; s < HS; ++s) gat(out_c, (unsigned)h[half].e, s * LANES) = emit_c[half][s];
+                for (int s = 0; s < HS; ++s) store_nt(gat(out_c, (unsigned)h[half].e, s * LANES), emit_c[half][s]);
             } else {
                 const int last = a.t_out - 1;
 #pragma unroll

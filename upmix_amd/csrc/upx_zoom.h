@@ -496,7 +496,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
         if (!a.accumulate) return;
         if (h.fast) {
 #pragma unroll
-            for (int s = 0; s < HS; ++s) old[s] = gat_u(plane, h.base + s * (long long)stride, h.o);
+            for (int s = 0; s < HS; ++s) old[s] = load_nt(gat_u(plane, h.base + s * (long long)stride, h.o));
         } else if (h.emit) {
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
@@ -507,7 +507,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     };
     auto emit = [&](UPX_GLOBAL float* plane, const Hop& h, int s, float v) {
         if (h.fast) {
-            gat_u(plane, h.base + s * (long long)stride, h.o) = v;
+            store_nt(gat_u(plane, h.base + s * (long long)stride, h.o), v);
         } else if (h.emit) {
             const long long left = (long long)a.t_out - (h.base + s * (long long)stride);
             if ((long long)h.o < left) gat_u(plane, h.base + s * (long long)stride, h.o) = v;
@@ -594,7 +594,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
         const long long b1 = role == 0 ? b0 : b0 + a.hop;
 #pragma unroll
         for (int s = 0; s < HS; ++s)
-            o8[s] = mk(gat_u(p0, b0 + s * (long long)stride, o), gat_u(p1, b1 + s * (long long)stride, o));
+            o8[s] = mk(load_nt(gat_u(p0, b0 + s * (long long)stride, o)), load_nt(gat_u(p1, b1 + s * (long long)stride, o)));
     };
     auto run = [&](auto in_tag, auto acc_tag) {
     constexpr bool IN = decltype(in_tag)::value;      // interior stream: unconditional loads / stores
