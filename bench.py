@@ -379,8 +379,9 @@ def main():
                 "algorithmic_bytes_per_launch": dom["algo_bytes"],
                 "bands_in_launch": dom["bands"],
                 "avg_launch_ms": dom["ms"],
-                "limiter": "not HBM: wave issue + LDS / memory latency at 2-4 waves per SIMD (DESIGN.md 5, 8); the "
-                           "`valu` object is the ceiling that binds",
+                "limiter": "not HBM bandwidth: VALU issue + LDS exchanges at 2-4 waves per SIMD, and for the fused kernels the "
+                           "in-order vector L1 (0.30 ms without global traffic vs 0.43 with, DESIGN.md 5, 8); the `valu` "
+                           "object is the ceiling that binds",
             },
             "launches": launches,
             "all_bands_algorithmic_GBps": round((ALGO_BYTES_IN + ALGO_BYTES_OUT) * n_bands * calls_samples
