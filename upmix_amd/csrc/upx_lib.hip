@@ -109,7 +109,12 @@ __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Ex = DevExec<C::WAVE_SYNC || C::WIDE, C::P>;
     Ex ex;
-    upx::band_program_auto<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    // the interior flavour (two more instantiations of the program) for the kernels plans select by default; the
+    // 8-points-per-lane and plain-schedule alternates (UPX_KERNEL_VARIANT) keep the one general body
+    if constexpr (C::P == 16 && (C::WIDE || C::LOG2N <= 11))
+        upx::band_program_auto<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    else
+        upx::band_program<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 
 __global__ void upx_stream_seam_add_kernel(upx::BandArgs a, int n_streams, int tail, int hop) {
