@@ -19,13 +19,15 @@ A "step" is one pass of the hot path over synthetic stereo already resident in H
   batch    configs[4]: 8 independent 5-min 48 kHz tracks per GPU (64 on 8 GPUs), C3 plan, replicas only (no
            communication); `value` = tracks resident in HBM, the PCIe-inclusive upx_process_tracks rate is in `e2e`.
 
-torch.distributed (gloo) is used only for the rendezvous, barriers and the max-over-ranks of the wall time; all GPU
-work goes through libupmix_hip.so.  Prints ONE JSON line on rank 0 (fields: README / DESIGN.md section 7).
+The ranks of an N > 1 run meet over upmix_amd.rendezvous (standard-library sockets on the launcher's MASTER_ADDR /
+MASTER_PORT: the 128-byte RCCL id, the barriers and the max-over-ranks of the wall time); this process never imports
+torch, all GPU work goes through libupmix_hip.so.  Prints ONE JSON line on rank 0 (fields: README / DESIGN.md section 7).
 """
 import argparse
 import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -105,6 +107,24 @@ def cpu_baseline(sr, max_stft, target_seconds=15.0):
     }
 
 
+def executed_flops_per_sample(kernel_name, n, k, n_bands_in_launch, phase):
+    """
+    Flops of the transforms a launch actually runs, per stereo sample (model, same 5 n log2 n per complex transform
+    as SURVEY.md 8(d)): a fused launch runs 2.5 complex N-point transforms per frame and K frames cover a sample ->
+    12.5 K log2 N (+ 80 for the mask, per band carried); the band-limited pair runs D transforms of P points where a
+    full-size path runs one of N = D P points -> 5 K log2 P for the analysis (+ 8 K for ramp and residue sum, + the
+    mask over P/2 of N/2 bins per band), 7.5 K log2 P (+ 9 K for the ramp) for the synthesis.  `phase`: 0 analysis,
+    1 synthesis / single kernel.  Unfused launches (upx_big_*) run full-size transforms.
+    """
+    m = re.search(r"ZoomCfg<(\d+), *(\d+), *(\d+)>", kernel_name)
+    if m:
+        p = 1 << int(m.group(1))
+        if phase == 0:
+            return 5.0 * k * np.log2(p) + 8.0 * k + 80.0 * n_bands_in_launch * p / n
+        return 7.5 * k * np.log2(p) + 9.0 * k
+    return 12.5 * k * np.log2(n) + 80.0 * n_bands_in_launch
+
+
 def load_pmc_traffic(kernel_tag):
     """
     HBM bytes per launch of `kernel_tag` from the committed rocprofv3 PMC summary (profiles/pmc_traffic.json) - only
@@ -146,9 +166,19 @@ def e2e_rates(ux, plan, bands, sr, nominal):
     run(warm)
     dt = timed(lambda: run(warm))
     out["upx_process_warm_buffers"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1)}
-    # ... and into fresh NumPy arrays (the kernel has to fault in and zero the new pages)
+    # ... into fresh pageable NumPy arrays (the kernel has to fault in and zero the new pages, and unmap them after) ...
     dt = timed(lambda: run([np.empty(nominal, dtype=np.float32) for _ in range(3)]))
-    out["upx_process_fresh_arrays"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1)}
+    out["upx_process_fresh_pageable_arrays"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1)}
+    # ... and what the drop-in entry does: fresh result arrays from the pool of page-locked blocks (upmix_amd/hostmem.py;
+    # the first call pins its blocks, later calls reuse the blocks of results that have been dropped)
+    t0 = time.perf_counter()
+    res = plan.process(x)
+    first = time.perf_counter() - t0
+    del res
+    dt = timed(lambda: plan.process(x))
+    out["upx_process_fresh_arrays"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1),
+                                       "first_call_ms": round(first * 1e3, 2),
+                                       "note": "DevicePlan.process: new result arrays per call, in pooled page-locked memory"}
     # WAV pipeline: PCM16 in, decode + all bands + peak scale + stereo_sum layout + quantisation on the device, PCM16 out
     pcm = np.clip(np.rint(x * 32767.0), -32768, 32767).astype("<i2")
     del x
@@ -159,7 +189,7 @@ def e2e_rates(ux, plan, bands, sr, nominal):
     out["upx_wav_pipeline_pcm16_stereo_sum"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1),
                                                 "h2d_ms": round(t["h2d"], 2), "device_ms": round(t["device"], 2),
                                                 "d2h_ms": round(t["d2h"], 2)}
-    out["note"] = ("pageable host buffers; best of 3; PCIe-inclusive, reported beside `value` (which is HBM-resident), "
+    out["note"] = ("pageable input buffers; best of 3; PCIe-inclusive, reported beside `value` (which is HBM-resident), "
                    "SURVEY.md 8(d)")
     return out
 
@@ -183,12 +213,8 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from upmix_amd.rendezvous import Rendezvous
+    group = Rendezvous.from_env()    # rank 0 listens, the others connect; world == 1: no socket
 
     import upmix_amd as ux
     from upmix_amd import sharding, _lib
@@ -248,24 +274,22 @@ def main():
         if world > 1 and os.environ.get("UPX_BENCH_REHEARSAL") == "1":
             # Rehearsal on a box with fewer GPUs than ranks (ranks share a device, which RCCL refuses): the seam goes
             # through host memory + gloo.  Exercises everything but RCCL; the JSON line says so and is not a result.
-            class _GlooSeam:
+            class _HostSeam:
                 def exchange(self, planes, own_len, spill_):
-                    import torch
                     host = [np.empty(own_len + spill_, dtype=np.float32) for _ in range(3)]
                     for h, d in zip(host, planes):
                         plan.d2h(h, d)
-                    seam = sharding.pack_seam(host, shard, world, spill_)
-                    t = torch.from_numpy(seam)
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-                    sharding.apply_seam(host, shard, t.numpy())
+                    mine = sharding.pack_seam(host, shard, world, spill_)
+                    rows = [np.frombuffer(b, dtype=np.float32).reshape(mine.shape) for b in group.allgather_bytes(mine.tobytes())]
+                    sharding.apply_seam(host, shard, np.sum(rows, axis=0, dtype=np.float32))
                     for h, d in zip(host, planes):
                         plan.h2d(d, h)
 
                 def close(self):
                     pass
-            comm = _GlooSeam()
+            comm = _HostSeam()
         elif world > 1:
-            comm = sharding.RcclSeam(plan, rank, world, broadcast=lambda b: sharding.broadcast_bytes_gloo(dist, b))
+            comm = sharding.RcclSeam(plan, rank, world, broadcast=group.broadcast_bytes)
 
         def step():
             plan.process_device(d_in, t_in, own, d_out[0], d_out[1], d_out[2], t_out)
@@ -275,8 +299,7 @@ def main():
 
     def barrier():
         plan.sync()
-        if dist is not None:
-            dist.barrier()
+        group.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -288,14 +311,8 @@ def main():
     for _ in range(args.steps):
         step()
     plan.sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    group.barrier()
+    elapsed = group.allreduce_max([time.perf_counter() - t0])[0]    # the slowest rank's time
     n_calls = min(64, args.steps * calls_per_step)          # the most recent timed process_device calls
     per_call = plan.band_times_calls_ms(n_calls) if n_calls else np.zeros((0, n_bands), np.float32)
     band_ms = per_call.mean(axis=0) if n_calls else np.zeros(n_bands)
@@ -319,25 +336,41 @@ def main():
         # band-limited launch its 8 B (analysis reads the input) and 12 B (synthesis writes Ls/C/Rs); merged bands
         # multiply.  `ms` = average launch time per process_device call (HIP events, same stream as the kernels).
         launches = []
+        hops = [b.hop_size for b in bands]
         for g, n in sorted(groups.items()):
             label = f"bands {g}..{g + n - 1} (STFT {sizes[g]})"
+            k_ov = -(-sizes[g] // hops[g])
             a_name = plan.band_phase_kernel_name(g, 0)
             if a_name:
+                s_name = plan.band_phase_kernel_name(g, 1)
                 launches.append({"kernel": a_name, "bands": label, "ms": float(ana_sum[g]) / n_calls,
-                                 "algo_bytes": ALGO_BYTES_IN * own * n})
-                launches.append({"kernel": plan.band_phase_kernel_name(g, 1), "bands": label,
-                                 "ms": float(syn_sum[g]) / n_calls, "algo_bytes": ALGO_BYTES_OUT * own * n})
+                                 "algo_bytes": ALGO_BYTES_IN * own * n,
+                                 "flops_executed": executed_flops_per_sample(a_name, sizes[g], k_ov, n, 0) * own})
+                launches.append({"kernel": s_name, "bands": label,
+                                 "ms": float(syn_sum[g]) / n_calls, "algo_bytes": ALGO_BYTES_OUT * own * n,
+                                 "flops_executed": executed_flops_per_sample(s_name, sizes[g], k_ov, n, 1) * own})
             else:
-                launches.append({"kernel": plan.band_kernel_name(g), "bands": label, "ms": float(band_ms[g]),
-                                 "algo_bytes": (ALGO_BYTES_IN + ALGO_BYTES_OUT) * own * n})
+                name = plan.band_kernel_name(g)
+                launches.append({"kernel": name, "bands": label, "ms": float(band_ms[g]),
+                                 "algo_bytes": (ALGO_BYTES_IN + ALGO_BYTES_OUT) * own * n,
+                                 "flops_executed": executed_flops_per_sample(name, sizes[g], k_ov, n, 1) * own})
         for L in launches:
             L["GBps"] = round(L["algo_bytes"] / (L["ms"] * 1e-3) / 1e9, 1) if L["ms"] > 0 else None
             L["frac"] = round(L["GBps"] / HBM_PEAK_GBPS, 4) if L["GBps"] else None
+            # executed arithmetic of this launch against the f32 vector peak, and its HBM traffic from the PMC counters
+            L["flops_executed"] = float(round(L["flops_executed"]))
+            L["TFLOPs"] = round(L["flops_executed"] / (L["ms"] * 1e-3) / 1e12, 2) if L["ms"] > 0 else None
+            L["valu_frac"] = round(L["TFLOPs"] / VALU_PEAK_TFLOPS, 4) if L["TFLOPs"] else None
+            L["traffic"], note = load_pmc_traffic(L["kernel"])
+            L["traffic_ratio"] = round(L["traffic"] / L["algo_bytes"], 3) if L["traffic"] else None
+            if note:
+                L["traffic_note"] = note
             L["ms"] = round(L["ms"], 4)
         dom = max(launches, key=lambda L: L["ms"])
         traffic, traffic_note = load_pmc_traffic(dom["kernel"])
         kernel_ms = float(band_ms.sum())
         flops_per_sample = 50.0 * sum(np.log2(n) for n in sizes) + 80.0 * n_bands
+        flops_executed = sum(L["flops_executed"] for L in launches)
         calls_samples = own                                                            # samples per process_device call
         out = {
             "metric": "stereo Msamples/sec upmixed (6-band, STFT<=8192)",
@@ -367,7 +400,8 @@ def main():
             },
             "median_kernel_ms_per_step": None if median_ms is None else round(median_ms, 4),
             "roofline": {
-                "bound": "hbm",
+                "bound": "hbm (prescribed)",
+                "binding_ceiling": "fp32 vector issue (valu.executed, launches[].valu_frac) - not HBM bandwidth",
                 "kernel": dom["kernel"],
                 "achieved": dom["GBps"],
                 "peak": HBM_PEAK_GBPS,
@@ -379,9 +413,9 @@ def main():
                 "algorithmic_bytes_per_launch": dom["algo_bytes"],
                 "bands_in_launch": dom["bands"],
                 "avg_launch_ms": dom["ms"],
+                "traffic_ratio": dom["traffic_ratio"],
                 "limiter": "not HBM bandwidth: VALU issue + LDS exchanges at 2-4 waves per SIMD, and for the fused kernels the "
-                           "in-order vector L1 (0.30 ms without global traffic vs 0.43 with, DESIGN.md 5, 8); the `valu` "
-                           "object is the ceiling that binds",
+                           "in-order vector L1 (DESIGN.md 5, 8); `valu.executed` is the ceiling that binds",
             },
             "launches": launches,
             "all_bands_algorithmic_GBps": round((ALGO_BYTES_IN + ALGO_BYTES_OUT) * n_bands * calls_samples
@@ -389,11 +423,23 @@ def main():
             "all_bands_frac": round((ALGO_BYTES_IN + ALGO_BYTES_OUT) * n_bands * calls_samples
                                     / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if kernel_ms > 0 else None,
             "valu": {
-                "flops_per_sample": round(flops_per_sample, 1),
-                "formula": "50 * sum_b log2 N_b + 80 * bands (SURVEY.md 8(d): algorithmic, full-size transforms)",
-                "achieved": round(flops_per_sample * calls_samples / (kernel_ms * 1e-3) / 1e12, 2) if kernel_ms > 0 else None,
+                # what the SIMDs execute: the transforms actually run (P-point ones on the band-limited path)
+                "executed": {
+                    "flops_per_sample": round(flops_executed / calls_samples, 1),
+                    "formula": "per launch: fused 12.5 K log2 N + 80 bands; band-limited analysis 5 K log2 P + 8 K + "
+                               "80 bands P/N, synthesis 7.5 K log2 P + 9 K (K = N / hop); launches[].flops_executed",
+                    "achieved": round(flops_executed / (kernel_ms * 1e-3) / 1e12, 2) if kernel_ms > 0 else None,
+                    "frac": round(flops_executed / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4) if kernel_ms > 0 else None,
+                },
+                # the same time priced at what full-size transforms for every band would cost: a
+                # speed-up figure for the pruned path, NOT a utilisation (it can exceed the peak)
+                "band_equivalent": {
+                    "flops_per_sample": round(flops_per_sample, 1),
+                    "formula": "50 * sum_b log2 N_b + 80 * bands (SURVEY.md 8(d): algorithmic, full-size transforms)",
+                    "achieved": round(flops_per_sample * calls_samples / (kernel_ms * 1e-3) / 1e12, 2) if kernel_ms > 0 else None,
+                    "frac_of_peak_equivalent": round(flops_per_sample * calls_samples / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4) if kernel_ms > 0 else None,
+                },
                 "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(flops_per_sample * calls_samples / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4) if kernel_ms > 0 else None,
             },
             "kernel_sources_sha256_16": kernel_sources_sha(),
         }
@@ -401,14 +447,23 @@ def main():
             try:
                 if batch:
                     tracks = [synth(nominal, (4, t)) for t in range(TRACKS_PER_GPU)]
-                    plan.process_tracks(tracks[:1])
                     t0 = time.perf_counter()
-                    plan.process_tracks(tracks)
-                    dt = time.perf_counter() - t0
-                    out["e2e"] = {"upx_process_tracks": {"ms": round(dt * 1e3, 1), "tracks": TRACKS_PER_GPU,
-                                                         "Msamples_per_s": round(nominal * TRACKS_PER_GPU / dt / 1e6, 1)},
-                                  "note": "pageable host buffers, fresh output arrays; uploads, kernels and downloads "
-                                          "of consecutive tracks overlap; PCIe-inclusive (never `value`)"}
+                    res = plan.process_tracks(tracks)
+                    first = time.perf_counter() - t0
+                    del res
+                    best = None
+                    for _ in range(3):
+                        t0 = time.perf_counter()
+                        res = plan.process_tracks(tracks)
+                        dt = time.perf_counter() - t0
+                        del res
+                        best = dt if best is None or dt < best else best
+                    out["e2e"] = {"upx_process_tracks": {"ms": round(best * 1e3, 1), "tracks": TRACKS_PER_GPU,
+                                                         "Msamples_per_s": round(nominal * TRACKS_PER_GPU / best / 1e6, 1),
+                                                         "first_call_ms": round(first * 1e3, 1)},
+                                  "note": "pageable input arrays, new result arrays per call in pooled page-locked memory "
+                                          "(the first call pins the blocks); uploads, kernels and downloads of consecutive "
+                                          "tracks overlap; best of 3; PCIe-inclusive (never `value`)"}
                     del tracks
                 else:
                     out["e2e"] = e2e_rates(ux, plan, bands, sr, nominal)
@@ -424,14 +479,9 @@ def main():
 
     if comm is not None:
         comm.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-        # torch (bundled HIP runtime) and libupmix_hip.so (system HIP runtime) share this process: leave without
-        # running the interpreter's teardown, where the two runtimes' exit handlers can collide
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+    group.barrier()
+    group.close()
+    plan.close()
 
 
 if __name__ == "__main__":

@@ -109,6 +109,12 @@ int upx_process_tracks(upx_plan* plan, int32_t n_tracks, const float* const* ste
 int upx_dev_alloc(upx_plan* plan, void** ptr, size_t bytes);
 int upx_dev_free(upx_plan* plan, void* ptr);
 int upx_dev_memset(upx_plan* plan, void* ptr, int value, size_t bytes);
+/* Page-locked host memory for the buffers a caller hands to upx_process / upx_process_tracks / upx_wav_*: copies to
+   and from it run at link speed, without the runtime's staging copy and without page faults of fresh pages (a call
+   into fresh pageable arrays spends most of its time there).  upmix_amd keeps a pool of such blocks and returns its
+   result arrays in them (the reference returns fresh NumPy arrays, center_extraction.py:503-513). */
+int upx_host_alloc(upx_plan* plan, void** ptr, size_t bytes);
+int upx_host_free(upx_plan* plan, void* ptr);
 int upx_copy_h2d(upx_plan* plan, void* dst_dev, const void* src_host, size_t bytes);
 int upx_copy_d2h(upx_plan* plan, void* dst_host, const void* src_dev, size_t bytes);
 int upx_sync(upx_plan* plan);
@@ -181,6 +187,21 @@ enum { UPX_PCM16 = 16, UPX_PCM24 = 24, UPX_PCM32 = 32, UPX_F32 = 1032 };
 enum { UPX_EXPORT_STEREO_SUM = 0, UPX_EXPORT_SPLIT = 1, UPX_EXPORT_AB = 2 };
 int upx_wav_pipeline(upx_plan* plan, const void* pcm_in, int in_format, int channels, int64_t n_frames, int mode,
                      int out_format, void* out0, void* out1, void* out2, double* stats);
+/*
+ * The same flow for ONE TIME SHARD of a file (one process per GPU; main.py:43-157 on a slice): the two
+ * scalars of main.py:53-55 / :85-88 are global, so the call is split where they cross the ranks.
+ *   begin   raw samples of the shard (t_in frames from its first owned one: own range + right halo) go up in pieces,
+ *           each decoded as it lands; all bands; the RCCL overlap-add seam if `comm` has more than one rank
+ *           (upx_comm_seam_exchange with `spill`; planes hold t_out >= own_len frames, own_len + spill for a shard with
+ *           a successor); then peaks[0] = max |input| and peaks[1] = max(|Ls|,|C|,|Rs|) over the OWNED frames (a NaN
+ *           anywhere gives NaN, as np.max does).  The caller takes the maximum of both over the ranks.
+ *   finish  planes * scale (main.py:95-97), export layout + quantisation on the device (as upx_wav_pipeline), the
+ *           final 2-channel sample data of the own_len owned frames comes down into out0..2.
+ * upx_wav_pipeline is begin + finish for a shard that is the whole file.
+ */
+int upx_wav_shard_begin(upx_plan* plan, upx_comm* comm, const void* pcm_in, int in_format, int channels, int64_t t_in,
+                        int64_t own_len, int64_t t_out, int64_t spill, double* peaks);
+int upx_wav_shard_finish(upx_plan* plan, double scale, int mode, int out_format, void* out0, void* out1, void* out2);
 /* Milliseconds spent in the last upx_wav_pipeline call: H2D, decode+kernels+peak+export, D2H. */
 int upx_wav_pipeline_times_ms(upx_plan* plan, float* ms3);
 

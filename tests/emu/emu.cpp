@@ -71,7 +71,7 @@ void turn_trig(double frac, double& c, double& s) {
 
 long long g_interior_wgs = 0;   // workgroups of the last emu_band() call that took band_program's interior flavour
 
-template <class C>
+template <class C, class LV = upx::LiveAll, bool MERGED = true>
 int run(upx::BandArgs a) {
     g_interior_wgs = 0;
     std::vector<upx::cf> tw((size_t)C::TW_CF);
@@ -97,7 +97,7 @@ int run(upx::BandArgs a) {
         // poison LDS so that reads of never-written cells are visible
         for (auto& v : lds) v = upx::mk(NAN, NAN);
         g_interior_wgs += upx::band_interior<C>(a, (int)wg) ? 1 : 0;
-        upx::band_program_auto<C>(ex, a, lds.data(), (int)wg);
+        upx::band_program_auto<C, decltype(ex), MERGED, LV>(ex, a, lds.data(), (int)wg);
     }
     for (long long g = 0; g < n_streams * tail; ++g) upx::stream_seam_add(a, (int)n_streams, tail, C::HOP, g);
     return 0;
@@ -129,6 +129,30 @@ extern "C" int emu_band(int log2n, int k_overlap, int pts, const float* in, long
 #define UPX_WIDE(L, K) if (log2n == L && k_overlap == K && pts == 0) return run<upx::WideCfg<L, K>>(a);
     UPX_WIDE(12, 4) UPX_WIDE(13, 4) UPX_WIDE(12, 2) UPX_WIDE(12, 8) UPX_WIDE(13, 2) UPX_WIDE(13, 8)
 #undef UPX_WIDE
+    return -1;
+}
+
+// The single-band flavour specialised for the live own-bin slots [s0, s1) (upx::Live<s0, s1>): same arguments as
+// emu_band with n_gain == 1; the caller guarantees that the gain vector is zero outside those slots.
+extern "C" int emu_band_live(int log2n, int k_overlap, int s0, int s1, const float* in, long long t_in, float* out_c,
+                             float* out_l, float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
+                             const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int blocks_per_stream,
+                             int accumulate) {
+    upx::BandArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const upx::cf*>(in);
+    a.out_c = out_c; a.out_l = out_l; a.out_r = out_r;
+    a.w_a = w_a; a.w_s = w_s_scaled; a.gain = gain_half;
+    a.t_in = (int)t_in; a.t_out = (int)t_out;
+    a.j_lo = j_lo; a.j_hi = j_hi; a.m_lo = m_lo; a.m_hi = m_hi;
+    a.blocks_per_stream = blocks_per_stream; a.accumulate = accumulate;
+    a.n_gain = 1; a.gain_stride = (1 << log2n) / 2 + 1;
+#define UPX_LIVE(L, K, A, B) \
+    if (log2n == L && k_overlap == K && s0 == A && s1 == B) return run<upx::Cfg<L, K, 16>, upx::Live<A, B>, false>(a);
+    UPX_LIVE(10, 4, 0, 2) UPX_LIVE(10, 4, 0, 3) UPX_LIVE(10, 4, 0, 4) UPX_LIVE(11, 4, 0, 2) UPX_LIVE(11, 4, 0, 3)
+    UPX_LIVE(11, 4, 0, 4) UPX_LIVE(8, 4, 1, 8) UPX_LIVE(9, 4, 1, 8) UPX_LIVE(10, 4, 1, 8) UPX_LIVE(10, 4, 0, 8)
+    UPX_LIVE(8, 4, 0, 5) UPX_LIVE(10, 2, 1, 6) UPX_LIVE(10, 8, 0, 1) UPX_LIVE(11, 4, 1, 2)
+#undef UPX_LIVE
     return -1;
 }
 

@@ -120,9 +120,8 @@ def test_process_tracks_equals_per_track_calls_and_oracle(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_rank_driver_on_gpu_and_failed_download_returns(monkeypatch):
+def test_rank_driver_on_gpu(monkeypatch):
     import upmix_amd as ux
-    from upmix_amd import _lib
     monkeypatch.setenv("UPX_STREAM_CHUNK", "16384")
     bands = ux.chain_bands([0, 300, 3000], 0.75, ux.make_blackman_harris, 48000, max_block_size=4096,
                            threshold_factor=64, verbose=False)
@@ -134,15 +133,74 @@ def test_rank_driver_on_gpu_and_failed_download_returns(monkeypatch):
     for i, planes in enumerate(whole):
         for g, a in zip(res[i], planes):
             assert np.array_equal(g, a)
-    # a failing download with work items left must surface as an error, not hang the call
-    monkeypatch.setenv("UPX_TEST_FAIL_DOWNLOAD", "1")
-    with pytest.raises(_lib.UpmixHipError, match="download of a work item failed"):
-        ux.process_tracks(tracks, bands)
-    monkeypatch.delenv("UPX_TEST_FAIL_DOWNLOAD")
-    again = ux.process_tracks(tracks, bands)      # the plan is usable afterwards
+    # (a failing download with work items left must surface as an error, not hang the call: the hand-over logic is
+    # tested with injected failures in tests/test_pipeline.py; the product library carries no injection hook)
+    again = ux.process_tracks(tracks, bands)
     for planes, ref in zip(again, whole):
         for g, a in zip(planes, ref):
             assert np.array_equal(g, a)
+
+
+@pytest.mark.gpu
+def test_c5_full_size_tracks():
+    """BASELINE configs[4], one GPU's share at full size: 8 tracks of 5 min (14.4 M samples each, seed (4, track)), the
+    6-band plan of configs[2], through upx_process_tracks: every track bit-equal to a upx_process call on it alone,
+    oracle windows (head / interior / tail) on two tracks."""
+    import upmix_amd as ux
+    edges, total = [0, 30, 120, 480, 1920, 7680], 14_400_000
+    bands = ux.chain_bands(edges, 0.75, ux.make_blackman_harris, 48000, max_block_size=8192, verbose=False)
+    ob = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, 48000, max_block_size=8192)
+    plan = ux.DevicePlan(bands)
+    tracks = [orc.synthetic_stereo(total, (4, t)) for t in range(8)]
+    got = plan.process_tracks(tracks)
+    assert len(got) == 8
+    for t, (x, planes) in enumerate(zip(tracks, got)):
+        alone = plan.process(x)
+        for g, a in zip(planes, alone):
+            assert g.shape == (total,) and np.array_equal(g, a), t
+        del alone
+    for t in (0, 5):
+        x, planes = tracks[t], got[t]
+        n = 50000
+        ref = orc.extract_multi_band(x[:n + 8192, 0].astype(np.float64), x[:n + 8192, 1].astype(np.float64), ob)
+        for g, r in zip(planes, ref):
+            assert rms(g[:n].astype(np.float64) - r[:n]) <= 1e-5
+        for a in (2048 * 3000, (total // 2048 - 40) * 2048):
+            seg = x[a:a + 90000].astype(np.float64)
+            ref = orc.extract_multi_band(seg[:, 0], seg[:, 1], ob)
+            hi = min(90000, len(seg))
+            end = hi - 8192 if a + 90000 < total else hi      # (the tail window runs to the end of the track)
+            for g, r in zip(planes, ref):
+                assert rms(g[a + 8192:a + end].astype(np.float64) - r[8192:end]) <= 1e-5
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_batch_cli_files_equal_cli_run(tmp_path, capsys):
+    """python -m upmix_amd.batch: every track's files are the files cli.run writes for that track alone (device codec
+    and --host-export), for files of two sample rates, mono and stereo, one with three channels (host flow)."""
+    from upmix_amd import cli, wav
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "in"))
+    specs = [("a.wav", 120000, 48000, "PCM_16", 2), ("b.wav", 45000, 44100, "PCM_24", 2), ("c.wav", 70001, 48000, "FLOAT", 1),
+             ("d.wav", 30000, 48000, "PCM_16", 3)]
+    for name, n, sr, sub, ch in specs:
+        x = orc.synthetic_stereo(n, len(name) + n).astype(np.float64)
+        x = x[:, 0] if ch == 1 else (np.column_stack([x, 0.3 * x[:, 0]]) if ch == 3 else x)
+        wav.write(os.path.join(tmp, "in", name), x, sr, sub)
+    names = [s[0] for s in specs]
+    for mode, extra in (("stereo_sum", []), ("split", []), ("AB", ["--host-export"])):
+        out_b = os.path.join(tmp, f"batch_{mode}")
+        assert batch.main(names + ["--in-dir", os.path.join(tmp, "in"), "--out-dir", out_b, "--export-mode", mode,
+                                   "--max-stft", "8192", "--subtype", "PCM_24"] + extra) == 0
+        for name in names:
+            ref = cli.run(name, mode, os.path.join(tmp, "in"), os.path.join(tmp, f"cli_{mode}"), max_stft=8192,
+                          subtype="PCM_24", host_export=bool(extra) or name == "d.wav")
+            assert ref
+            for key, path in ref.items():
+                assert open(path, "rb").read() == open(os.path.join(out_b, os.path.basename(path)), "rb").read(), \
+                    (mode, name, key)
+    capsys.readouterr()
 
 
 @pytest.mark.gpu

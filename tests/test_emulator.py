@@ -251,3 +251,73 @@ def test_merged_bands_equal_band_sum(emu):
     ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), bands)
     for g, r in zip(got, ref):
         assert rms(g.astype(np.float64) - r) < 1e-7
+
+
+# ---- live-slot flavours (upx::Live<S0, S1>: pruned mask / parking / butterflies) --------------------------------
+def live_slots(band, lanes):
+    """Own-bin slots [s0, s1) that carry gain (slot s = bins lane + s * lanes), s1 = 8 if the Nyquist bin does."""
+    g = orc.band_gain(band)
+    n = band.block_size
+    live = [bool(np.any(g[s * lanes:(s + 1) * lanes] != 0)) for s in range(8)]
+    s0 = min(i for i, v in enumerate(live) if v)
+    s1 = max(i for i, v in enumerate(live) if v) + 1
+    if g[n // 2] != 0:
+        s1 = 8
+    return s0, s1
+
+
+LIVE_CASES = [  # N, overlap, f_low, f_high, width_low, width_high, sr, instantiated (s0, s1)
+    (1024, 0.75, 1920., 7680., 480., 1920., 48000, (0, 4)),    # BASELINE configs[2] band 5: bins 31..205
+    (1024, 0.75, 1920., 7000., 480., 1500., 48000, (0, 3)),
+    (1024, 0.75, 1920., 5000., 480., 100., 48000, (0, 2)),
+    (2048, 0.75, 1920., 7680., 480., 1920., 96000, (0, 2)),    # configs[3] band 5
+    (2048, 0.75, 1920., 7680., 480., 1920., 96000, (0, 3)),    # ... through a wider instantiation
+    (2048, 0.75, 1920., 14000., 480., 2000., 96000, (0, 4)),
+    (256, 0.75, 7680., 24000., 1920., 6000., 48000, (1, 8)),   # configs[2] band 6 (Nyquist live)
+    (512, 0.75, 9000., 48000., 1920., 12000., 96000, (1, 8)),
+    (1024, 0.75, 6000., 24000., 1000., 6000., 48000, (1, 8)),
+    (1024, 0.75, 0., 24000., 0., 6000., 48000, (0, 8)),        # full range through the same entry point
+    (256, 0.75, 0., 6000., 0., 500., 48000, (0, 5)),           # DC live, Nyquist dead
+    (1024, 0.5, 4000., 15000., 400., 800., 48000, (1, 6)),
+    (1024, 0.875, 40., 2000., 10., 200., 48000, (0, 1)),
+    (2048, 0.75, 3800., 5300., 300., 300., 48000, (1, 2)),
+]
+
+
+@pytest.mark.parametrize("case", LIVE_CASES, ids=[f"N{c[0]}_{c[7][0]}_{c[7][1]}" for c in LIVE_CASES])
+def test_live_slot_flavours(emu, case, pts):
+    """The pruned flavour must give what the general one gives (skipped terms are exact zeros) and the oracle's result,
+    for first bands and accumulating ones, interior and edge workgroups."""
+    if pts != 16:
+        pytest.skip("live-slot flavours exist for 16 points per lane")
+    n, ov, lo, hi, wl, wh, sr, (s0, s1) = case
+    band = orc.Band(n, ov, lo, hi, sr, "raised_cosine", wl, wh)
+    lanes = n // 16
+    a0, a1 = live_slots(band, lanes)
+    assert s0 <= a0 and a1 <= s1, ("the instantiation must cover the live slots", (a0, a1))
+    emu.emu_band_live.argtypes = [ctypes.c_int] * 4 + [fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong, fp, fp, fp] + \
+        [ctypes.c_int] * 6
+    emu.emu_band_live.restype = ctypes.c_int
+    hop = band.hop_size
+    k = n // hop
+    total = 40 * hop + 77
+    x = orc.synthetic_stereo(total, n + s1)
+    ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+    w_a = np.ascontiguousarray(band.analysis_window)
+    w_s = (band.synthesis_window / np.float32(n)).astype(np.float32)
+    gain = np.ascontiguousarray((0.5 * orc.band_gain(band)).astype(np.float32))
+    xin = np.ascontiguousarray(x, dtype=np.float32)
+    j_hi = -(-total // hop)
+    for accumulate in (0, 1):
+        base = [np.full(total, 0.25 if accumulate else np.nan, np.float32) for _ in range(3)]
+        m_hi = min(j_hi + k - 1, -(-total // hop)) if accumulate else -(-total // hop)
+        general = run_emu(emu, band, x, 6, outs=[b.copy() for b in base], accumulate=accumulate, pts=16)
+        got = [b.copy() for b in base]
+        rc = emu.emu_band_live(int(np.log2(n)), k, s0, s1, P(xin), total, P(got[0]), P(got[1]), P(got[2]), total, P(w_a),
+                               P(w_s), P(gain), 0, j_hi, 0, m_hi, 6, accumulate)
+        assert rc == 0
+        for g, q, r in zip(got, general, ref):
+            assert not np.isnan(g).any()
+            # (the single-band flavour evaluates the mask through mask_weight: same numbers up to float32 rounding)
+            assert float(np.max(np.abs(g - q))) <= 3e-7, "pruned flavour differs from the general one"
+            assert rms(g.astype(np.float64) - (r + (0.25 if accumulate else 0.0))) < 1e-7

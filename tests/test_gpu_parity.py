@@ -206,6 +206,40 @@ def test_c2_prefix_vs_oracle(ux, orc):
         close(got, r)
 
 
+def test_c2_full_size(ux, orc):
+    """BASELINE configs[1] whole: 60 s of 48 kHz stereo (2.88 M samples), 3 bands (crossovers 300 / 3000 Hz), STFT
+    [4096, 4096, 1024], seed 1: oracle windows at the head, in the interior and at the tail, time shards + seams ==
+    single launch, silence -> exact zeros."""
+    total = 2_880_000
+    x = orc.synthetic_stereo(total, 1)
+    bands = gpu_chain(ux, [0, 300, 3000], 48000, 4096, 64)
+    ob = orc.plan_bands([0, 300, 3000], 0.75, orc.win_blackman_harris, 48000, max_block_size=4096, threshold_factor=64)
+    assert [b.block_size for b in bands] == [4096, 4096, 1024]
+    out = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 48000, bands)
+    assert all(o.shape == (total,) and np.all(np.isfinite(o)) for o in out)
+    n = 120000
+    ref = orc.extract_multi_band(x[:n + 4096, 0].astype(np.float64), x[:n + 4096, 1].astype(np.float64), ob)
+    for got, r in zip(out, ref):
+        close(got[:n], r[:n])
+    for a in (1024 * 700, 1024 * 1999):          # interior windows on the hop_max grid (the restarted oracle fades in)
+        seg = x[a:a + 100000].astype(np.float64)
+        ref = orc.extract_multi_band(seg[:, 0], seg[:, 1], ob)
+        for got, r in zip(out, ref):
+            close(got[a + 4096:a + 100000 - 4096], r[4096:100000 - 4096])
+    a = (total // 1024 - 60) * 1024
+    seg = x[a:].astype(np.float64)
+    ref = orc.extract_multi_band(seg[:, 0], seg[:, 1], ob)
+    for got, r in zip(out, ref):
+        close(got[a + 4096:], r[4096:])
+    from upmix_amd.sharding import process_sharded_single_device
+    plan = ux.DevicePlan(bands)
+    for a, b in zip(out, process_sharded_single_device(plan, x, max_shard=700_000)):
+        assert rms(a.astype(np.float64) - b) < 1e-8 and float(np.max(np.abs(a - b))) < 1e-6
+    for o in plan.process(np.zeros((total, 2), np.float32)):
+        assert not o.any()
+    plan.close()
+
+
 @pytest.fixture(scope="module")
 def c3_full(ux, orc):
     """BASELINE configs[2] at full size: 10 min, 48 kHz, 6 bands, STFT <= 8192, seed 2."""

@@ -1,9 +1,11 @@
 """
 upmix_amd.multi_gpu (one WAV over the GPUs of a node, BASELINE configs[3]): every rank reads only its time shard and
 writes only its slice of each output file; the ranks agree on ONE scale through a max all-reduce of two scalars.
-CPU: world_size 2 over gloo with the ORACLE as engine and a gloo all-reduce as the seam (the RCCL seam has the same
-algebra, tests/test_sharding.py), compared byte for byte with the single-process host flow (cli.run --host-export,
-itself pinned to main.py by fixture F7).  GPU (-m gpu): world 1 through the real entry point.
+CPU: world_size 2 with the ORACLE as engine - once over torch.distributed gloo (a gloo all-reduce as the seam; the RCCL
+seam has the same algebra, tests/test_sharding.py) and once over the product's own process group
+(upmix_amd.rendezvous: sockets, plain multiprocessing) - compared byte for byte with the single-process host flow
+(cli.run --host-export, itself pinned to main.py by fixture F7).  GPU (-m gpu): world 1 through the real entry point,
+device pipeline == cli.run for every export mode and subtype.
 """
 import os
 import socket
@@ -27,10 +29,47 @@ def oracle_bands():
     return orc.plan_bands(EDGES, 0.75, orc.win_blackman_harris, 48000, max_block_size=1024)
 
 
-def oracle_engine(bands, world, dist):
+class GlooGroup:
+    """The process-group interface multi_gpu.run_rank expects, over torch.distributed gloo (test infrastructure)."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+
+    def allreduce_max(self, values):
+        import torch
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    def allreduce_sum_f32(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def all_ok(self, ok=True, message=""):
+        import torch
+        t = torch.tensor([0 if ok else 1])
+        self.dist.all_reduce(t)
+        if int(t.item()):
+            raise RuntimeError(message or "a rank failed")
+
+
+def socket_sum(group):
+    """float32 sum over the ranks through allgather_bytes (what bench.py's rehearsal seam does)."""
+    def run(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        rows = [np.frombuffer(b, dtype=np.float32).reshape(a.shape) for b in group.allgather_bytes(a.tobytes())]
+        return np.sum(rows, axis=0, dtype=np.float32)
+    return run
+
+
+def oracle_engine(bands, world, allreduce_sum):
     """(center, left, right) of a shard with the oracle; the seam all-reduce goes over the process group."""
     def run(local, shard, geo):
-        import torch
         planes = [np.zeros(shard.t_out, np.float32) for _ in range(3)]
         for b in bands:
             res = orc.band_process(local[:, 0].astype(np.float64), local[:, 1].astype(np.float64), b,
@@ -38,18 +77,24 @@ def oracle_engine(bands, world, dist):
             for f, r in zip(planes, res):
                 f += r
         if world > 1:
-            t = torch.from_numpy(sharding.pack_seam(planes, shard, world, geo.spill))
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            sharding.apply_seam(planes, shard, t.numpy())
+            seam = allreduce_sum(sharding.pack_seam(planes, shard, world, geo.spill))
+            sharding.apply_seam(planes, shard, seam)
         return tuple(p[:shard.own_len].copy() for p in planes)
     return run
 
 
-def _worker(rank, world, port, tmp, mode):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _worker(rank, world, port, tmp, mode, transport="gloo"):
+    if transport == "gloo":
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        group = GlooGroup(dist, rank, world)
+        allreduce_sum = group.allreduce_sum_f32
+    else:
+        from upmix_amd.rendezvous import Rendezvous
+        group = Rendezvous(rank, world, "127.0.0.1", port, timeout=120)
+        allreduce_sum = socket_sum(group)
     bands = oracle_bands()
     reads = []
     real_read_range = wav.read_range
@@ -59,25 +104,44 @@ def _worker(rank, world, port, tmp, mode):
         return real_read_range(path, start, count, meta)
     wav.read_range = spy
     multi_gpu.run_rank(os.path.join(tmp, "in", "song.wav"), os.path.join(tmp, f"out_{mode}"), mode, bands, 0.75,
-                       "PCM_16", rank, world, dist, engine=oracle_engine(bands, world, dist), log=lambda *_: None)
+                       "PCM_16", rank, world, group, engine=oracle_engine(bands, world, allreduce_sum),
+                       log=lambda *_: None)
     # the rank touched its own shard (+ halo) of the input and nothing else
     geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
     shard = geo.plan(41000, world)[rank]
     assert reads == [(shard.start, shard.t_in)], reads
-    dist.barrier()
-    dist.destroy_process_group()
+    group.barrier()
+    if transport == "gloo":
+        group.dist.destroy_process_group()
+    else:
+        group.close()
 
 
-@pytest.mark.parametrize("mode", ["stereo_sum", "split", "AB"])
-def test_two_rank_gloo_files_equal_single_process(tmp_path, mode):
-    import torch.multiprocessing as mp
-    tmp = str(tmp_path)
-    os.makedirs(os.path.join(tmp, "in"))
-    make_wav(os.path.join(tmp, "in", "song.wav"))
+def _spawn_two(tmp, mode, transport):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, tmp, mode), nprocs=2, join=True)
+    if transport == "gloo":
+        import torch.multiprocessing as tmp_mp
+        tmp_mp.spawn(_worker, args=(2, port, tmp, mode, transport), nprocs=2, join=True)
+    else:
+        import multiprocessing
+        ctx = multiprocessing.get_context("spawn")
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, mode, transport)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+
+
+@pytest.mark.parametrize("mode,transport", [("stereo_sum", "gloo"), ("split", "gloo"), ("AB", "gloo"),
+                                            ("stereo_sum", "sockets"), ("AB", "sockets")])
+def test_two_rank_files_equal_single_process(tmp_path, mode, transport):
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "in"))
+    make_wav(os.path.join(tmp, "in", "song.wav"))
+    _spawn_two(tmp, mode, transport)
     # single process, same engine: the reference flow of main.py on the oracle's planes
     bands = oracle_bands()
     wave, sr = wav.read(os.path.join(tmp, "in", "song.wav"))
@@ -118,18 +182,37 @@ def test_world_one_without_process_group(tmp_path):
 
 @pytest.mark.gpu
 def test_multi_gpu_entry_world_one_equals_cli(tmp_path, monkeypatch, capsys):
-    """The product entry with one rank writes the files cli.run --host-export writes (byte for byte)."""
+    """The product entry with one rank (device pipeline: upx_wav_shard_begin / _finish, page-locked staging) writes the
+    files cli.run writes with the device codec, byte for byte, for every export mode and subtype; its --host-export
+    flow writes the files of cli.run --host-export."""
     tmp = str(tmp_path)
     os.makedirs(os.path.join(tmp, "in"))
     make_wav(os.path.join(tmp, "in", "song.wav"), total=300000)
+    make_wav(os.path.join(tmp, "in", "mono24.wav"), total=150000, seed=32, subtype="PCM_24")
+    x, sr = wav.read(os.path.join(tmp, "in", "mono24.wav"))
+    wav.write(os.path.join(tmp, "in", "mono24.wav"), x[:, 0], sr, "PCM_24")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
+    n = 0
+    for name in ("song.wav", "mono24.wav"):
+        for mode in ("stereo_sum", "split", "AB"):
+            for subtype in ("PCM_16", "PCM_24", "PCM_32", "FLOAT"):
+                out_mg, out_cli = os.path.join(tmp, f"mg_{subtype}"), os.path.join(tmp, f"cli_{subtype}")
+                assert multi_gpu.main([name, "--export-mode", mode, "--in-dir", os.path.join(tmp, "in"), "--out-dir", out_mg,
+                                       "--max-stft", "8192", "--subtype", subtype]) == 0
+                ref = cli.run(name, mode, os.path.join(tmp, "in"), out_cli, max_stft=8192, subtype=subtype)
+                assert ref
+                for key, path in ref.items():
+                    other = os.path.join(out_mg, os.path.basename(path))
+                    assert open(path, "rb").read() == open(other, "rb").read(), (name, mode, subtype, key)
+                    n += 1
+    assert n == 2 * (1 + 3 + 1) * 4
     for mode in ("stereo_sum", "AB"):
         assert multi_gpu.main(["song.wav", "--export-mode", mode, "--in-dir", os.path.join(tmp, "in"), "--out-dir",
-                               os.path.join(tmp, "out_mg"), "--max-stft", "8192"]) == 0
-        ref = cli.run("song.wav", mode, os.path.join(tmp, "in"), os.path.join(tmp, "out_cli"), max_stft=8192,
+                               os.path.join(tmp, "out_mg_host"), "--max-stft", "8192", "--host-export"]) == 0
+        ref = cli.run("song.wav", mode, os.path.join(tmp, "in"), os.path.join(tmp, "out_cli_host"), max_stft=8192,
                       host_export=True)
         for key, path in ref.items():
-            other = os.path.join(tmp, "out_mg", os.path.basename(path))
+            other = os.path.join(tmp, "out_mg_host", os.path.basename(path))
             assert open(path, "rb").read() == open(other, "rb").read(), (mode, key)
     capsys.readouterr()

@@ -1,0 +1,100 @@
+"""
+upmix_amd.rendezvous: the process group of the one-process-per-GPU entries on standard-library sockets (no torch in
+the product path).  World 2 and 3 with plain multiprocessing, started before anything touches a GPU: broadcast of
+the RCCL id's 128 bytes, barrier, max of doubles (NaN propagates), failure propagation (every rank raises), and
+multi_gpu.run_rank over it with the oracle as engine.
+"""
+import math
+import multiprocessing as mp
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from upmix_amd import rendezvous
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _ops(rank, world, port, q):
+    try:
+        with rendezvous.Rendezvous(rank, world, "127.0.0.1", port, timeout=60) as g:
+            uid = bytes(range(128)) if rank == 0 else None
+            got = g.broadcast_bytes(uid)
+            g.barrier()
+            mx = g.allreduce_max([float(rank), 10.0 - rank, 0.5])
+            nan = g.allreduce_max([float("nan") if rank == world - 1 else 1.0])
+            parts = g.allgather_bytes(bytes([rank]) * (rank + 1))
+            g.all_ok(True)
+            try:
+                g.all_ok(rank != 1, "rank one says no")
+                failed = None
+            except rendezvous.RendezvousError as exc:
+                failed = str(exc)
+            q.put((rank, got == bytes(range(128)), mx, math.isnan(nan[0]), [len(p) for p in parts], failed))
+    except Exception as exc:   # noqa: BLE001
+        q.put((rank, "error", repr(exc)))
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_collectives_over_sockets(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_ops, args=(r, world, port, q)) for r in range(world)]
+    for p in reversed(procs):      # rank 0 starts LAST: the others retry until it listens
+        p.start()
+    results = sorted(q.get(timeout=90) for _ in range(world))
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, ok, mx, nan_ok, lens, failed in results:
+        assert ok is True
+        assert mx == [float(world - 1), 10.0, 0.5]
+        assert nan_ok
+        assert lens == [r + 1 for r in range(world)]
+        assert failed is not None and "rank 1: rank one says no" in failed     # EVERY rank raised
+
+
+def test_single_rank_needs_no_socket():
+    g = rendezvous.Rendezvous(0, 1)
+    assert g.broadcast_bytes(b"abc") == b"abc"
+    assert g.allreduce_max([1.5, -2.0]) == [1.5, -2.0]
+    g.barrier()
+    g.all_ok(True)
+    with pytest.raises(rendezvous.RendezvousError):
+        g.all_ok(False, "boom")
+    g.close()
+
+
+def test_port_choice():
+    env = {"MASTER_PORT": "29400"}
+    assert rendezvous.default_port(env) == 29400
+    env["TORCHELASTIC_USE_AGENT_STORE"] = "True"     # torch.distributed.run keeps its own store on MASTER_PORT
+    assert rendezvous.default_port(env) == 29401
+    env["UPX_RDZV_PORT"] = "31000"
+    assert rendezvous.default_port(env) == 31000
+
+
+@pytest.mark.timeout(60)
+def test_missing_rank_times_out():
+    with pytest.raises(rendezvous.RendezvousError, match="did not connect"):
+        rendezvous.Rendezvous(0, 2, "127.0.0.1", free_port(), timeout=0.5)
+    with pytest.raises(rendezvous.RendezvousError, match="cannot reach rank 0"):
+        rendezvous.Rendezvous(1, 2, "127.0.0.1", free_port(), timeout=0.5)
+
+
+def test_product_path_does_not_import_torch():
+    """`grep -n "import torch" bench.py upmix_amd/` must be empty."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py")] + [os.path.join(root, "upmix_amd", f) for f in os.listdir(os.path.join(root, "upmix_amd"))
+                                               if f.endswith(".py")]
+    for path in files:
+        text = open(path).read()
+        assert "import torch" not in text and "os._exit" not in text, path

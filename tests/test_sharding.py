@@ -80,9 +80,7 @@ def _worker(rank, world, port, tmp):
         return t.numpy()
 
     out = sharding.run_shard(x, geo, shard, world, oracle_engine(bands), allreduce)
-    # also exercise the byte broadcast used for the RCCL unique id
-    blob = sharding.broadcast_bytes_gloo(dist, bytes(range(128)) if rank == 0 else None)
-    assert blob == bytes(range(128))
+    # (the byte broadcast of the RCCL unique id is upmix_amd.rendezvous': tests/test_rendezvous.py)
     np.savez(os.path.join(tmp, f"rank{rank}.npz"), start=shard.start, c=out[0], l=out[1], r=out[2])
     dist.barrier()
     dist.destroy_process_group()

@@ -44,6 +44,8 @@ SIGNATURES = {
     "upx_dev_alloc": (C.c_int, [C.c_void_p, vpp, C.c_size_t]),
     "upx_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "upx_dev_memset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "upx_host_alloc": (C.c_int, [C.c_void_p, vpp, C.c_size_t]),
+    "upx_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "upx_copy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "upx_copy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "upx_sync": (C.c_int, [C.c_void_p]),
@@ -62,6 +64,9 @@ SIGNATURES = {
     "upx_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]),
     "upx_wav_pipeline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "upx_wav_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                      C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
+    "upx_wav_shard_finish": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "upx_wav_pipeline_times_ms": (C.c_int, [C.c_void_p, f32p]),
     "upx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "upx_comm_create": (C.c_int, [vpp, C.c_void_p, C.c_int, C.c_int, C.c_char_p]),

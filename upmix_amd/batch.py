@@ -4,9 +4,12 @@ A batch of independent tracks over the GPUs of a node (BASELINE configs[4], SURV
 
 The reference handles one file per ``python main.py`` run (main.py:36-80: load, chain_bands, extract, scale,
 export); a batch is that flow once per file.  Here every rank (one process per GPU) takes the tracks
-``rank, rank + world, rank + 2 world, ...`` and pushes them through ONE band plan on its GPU with
-``upx_process_tracks`` (uploads, kernels and downloads of consecutive tracks overlap).  There is no data-path
-communication between ranks: no collective, no seam.
+``rank, rank + world, rank + 2 world, ...`` and pushes them through ONE band plan on its GPU.  The file entry
+(``main``) runs each track through the device codec (``upx_wav_pipeline``: raw samples up, decode, all bands, peak
+scale, export layout and quantisation on the GPU, final 2-channel data down) while a reader thread fetches the next
+file into page-locked memory and a writer thread stores the previous result; ``process_tracks_rank`` is the
+in-memory form (``upx_process_tracks``: uploads, kernels and downloads of consecutive tracks overlap).  There is no
+data-path communication between ranks: no collective, no seam, no process group.
 
     python -m upmix_amd.batch a.wav b.wav c.wav --export-mode stereo_sum
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \\
@@ -52,6 +55,25 @@ def process_tracks_rank(tracks: Sequence[np.ndarray], band_extractors, rank: int
     return dict(zip(mine, results))
 
 
+_SUBTYPE_KIND = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32, "FLOAT": 1032}
+
+
+def _host_flow(plan, path, meta, bands, a, out_dir, rank):
+    """main.py:43-157 with NumPy around the kernels: --host-export, more than two channels, formats the device codec
+    does not read."""
+    wave, sr = wav.read(path)
+    if wave.ndim == 1:
+        wave = np.column_stack([wave, wave])               # main.py:47-48
+    c, l, r = plan.process(np.ascontiguousarray(wave[:, :2], dtype=np.float32))   # main.py:49-50: columns 0 and 1
+    peak_in = export.input_peak(wave)                      # over every channel, like main.py:53
+    scale_factor, overall_peak = export.scale_to_input_peak(c, l, r, peak_in)
+    arrays = export.export_arrays(a.export_mode, c, l, r, wave[:, 0], wave[:, 1])
+    names = export.export_file_names(os.path.splitext(os.path.basename(path))[0], a.export_mode, bands, a.overlap)
+    jobs = [(os.path.join(out_dir, names[k]), arr) for k, arr in arrays.items()]
+    return (peak_in, overall_peak, scale_factor), [lambda p=p, arr=arr: wav.write(p, arr, sr, a.subtype) for p, arr in jobs], \
+        [p for p, _ in jobs]
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="upmix_amd.batch", description=__doc__.split("\n\n")[0])
     ap.add_argument("files", nargs="+", help="WAV files (paths, or names inside --in-dir)")
@@ -66,9 +88,11 @@ def main(argv=None) -> int:
     ap.add_argument("--threshold-factor", type=float, default=32)
     ap.add_argument("--xo-fraction", type=float, default=0.25)
     ap.add_argument("--subtype", default="PCM_16", choices=["PCM_16", "PCM_24", "PCM_32", "FLOAT"])
+    ap.add_argument("--host-export", action="store_true", help="decode / scale / export with NumPy on the host")
     a = ap.parse_args(argv)
 
-    from .extractor import chain_bands, process_tracks
+    from concurrent.futures import ThreadPoolExecutor
+    from .extractor import DevicePlan, chain_bands
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     device = int(os.environ.get("LOCAL_RANK", "0"))
@@ -79,35 +103,66 @@ def main(argv=None) -> int:
     mine = assign_tracks(len(paths), rank, world)
     os.makedirs(a.out_dir, exist_ok=True)
     edges = [float(v) for v in a.band_edges.split(",")]
+    metas = {i: wav.info(paths[i]) for i in mine}
+    known_mode = a.export_mode in export.EXPORT_MODES
+    if not known_mode:
+        print(f"Unknown export_mode '{a.export_mode}' -- no files written.")   # main.py:159-160
 
-    loaded = {}
-    for i in mine:
-        wave, sr = wav.read(paths[i])
-        if wave.ndim == 1:
-            wave = np.column_stack([wave, wave])           # main.py:47-48
-        loaded[i] = (wave, sr)
-        print(f"[rank {rank}] Loaded '{paths[i]}', sr={sr}, shape={wave.shape}")
-    for sr in sorted({sr for _, sr in loaded.values()}):
-        group = [i for i in mine if loaded[i][1] == sr]
-        bands = chain_bands(edges, a.overlap, WINDOW_FUNCS[a.window], sr, a.xover_mode, max_block_size=a.max_stft,
-                            threshold_factor=a.threshold_factor, xo_fraction=a.xo_fraction, device=device,
-                            verbose=rank == 0)
-        results = process_tracks([loaded[i][0] for i in group], bands, device=device)
-        for i, (c, l, r) in zip(group, results):
-            wave = loaded[i][0]
-            peak_in = export.input_peak(wave)
-            scale_factor, overall_peak = export.scale_to_input_peak(c, l, r, peak_in)
-            print(f"[rank {rank}] {os.path.basename(paths[i])}: Original peak = {peak_in:.4f}, "
-                  f"L/C/R peak = {overall_peak:.4f}, scale_factor = {scale_factor:.4f}")
-            arrays = export.export_arrays(a.export_mode, c, l, r, wave[:, 0], wave[:, 1])
-            if not arrays:
-                print(f"Unknown export_mode '{a.export_mode}' -- no files written.")   # main.py:159-160
-            names = export.export_file_names(os.path.splitext(os.path.basename(paths[i]))[0], a.export_mode, bands,
-                                             a.overlap)
-            for key, arr in arrays.items():
-                path = os.path.join(a.out_dir, names[key])
-                wav.write(path, arr, sr, a.subtype)
-                print(f"[rank {rank}] Wrote => {path}")
+    with ThreadPoolExecutor(max_workers=1) as reader, ThreadPoolExecutor(max_workers=1) as writer:
+        pending = []
+        for sr in sorted({m["rate"] for m in metas.values()}):
+            group = [i for i in mine if metas[i]["rate"] == sr]
+            bands = chain_bands(edges, a.overlap, WINDOW_FUNCS[a.window], sr, a.xover_mode, max_block_size=a.max_stft,
+                                threshold_factor=a.threshold_factor, xo_fraction=a.xo_fraction, device=device,
+                                verbose=rank == 0)
+            plan = DevicePlan(bands, device)
+            try:
+                def on_device(i):
+                    m = metas[i]
+                    try:
+                        wav.device_kind(m, paths[i])
+                    except ValueError:
+                        return False
+                    return known_mode and not a.host_export and m["channels"] in (1, 2) and 0 < m["n_frames"] < (1 << 29)
+
+                def fetch(i):   # reader thread: the file's sample bytes, undecoded, into page-locked memory
+                    m = metas[i]
+                    block = m["bits"] // 8 * m["channels"]
+                    return wav.read_raw_range(paths[i], 0, m["n_frames"], m, out=plan.host_empty(m["n_frames"] * block))
+
+                ahead = reader.submit(fetch, group[0]) if group and on_device(group[0]) else None
+                for pos, i in enumerate(group):
+                    m = metas[i]
+                    shape = (m["n_frames"], m["channels"]) if m["channels"] > 1 else (m["n_frames"],)
+                    print(f"[rank {rank}] Loaded '{paths[i]}', sr={sr}, shape={shape}")
+                    if on_device(i):
+                        raw = ahead.result()
+                        nxt = group[pos + 1] if pos + 1 < len(group) else None
+                        ahead = reader.submit(fetch, nxt) if nxt is not None and on_device(nxt) else None
+                        payloads, st = plan.wav_pipeline(raw, wav.device_kind(m), m["channels"], m["n_frames"],
+                                                         a.export_mode, _SUBTYPE_KIND[a.subtype])
+                        stats = (st["peak_in"], st["overall_peak"], st["scale_factor"])
+                        names = export.export_file_names(os.path.splitext(os.path.basename(paths[i]))[0], a.export_mode,
+                                                         bands, a.overlap)
+                        outs = [os.path.join(a.out_dir, names[k]) for k in payloads]
+                        jobs = [lambda p=p, b=b: wav.write_raw(p, b, sr, _SUBTYPE_KIND[a.subtype], 2)
+                                for p, b in zip(outs, payloads.values())]
+                    else:
+                        if pos + 1 < len(group) and on_device(group[pos + 1]) and ahead is None:
+                            ahead = reader.submit(fetch, group[pos + 1])
+                        stats, jobs, outs = _host_flow(plan, paths[i], m, bands, a, a.out_dir, rank) if known_mode else \
+                            ((float("nan"),) * 3, [], [])
+                    if known_mode:
+                        print(f"[rank {rank}] {os.path.basename(paths[i])}: Original peak = {stats[0]:.4f}, "
+                              f"L/C/R peak = {stats[1]:.4f}, scale_factor = {stats[2]:.4f}")
+                    for job, out in zip(jobs, outs):   # writer thread: the previous track's files while the next one runs
+                        pending.append((writer.submit(job), out))
+                for fut, out in pending:
+                    fut.result()
+                    print(f"[rank {rank}] Wrote => {out}")
+                pending.clear()
+            finally:
+                plan.close()
     print(f"[rank {rank}] Done ({len(mine)} of {len(paths)} tracks).")
     return 0
 

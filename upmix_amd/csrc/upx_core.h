@@ -86,6 +86,17 @@ UPX_PK2(mi_sub_conj, "v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_h
 UPX_PK2(swap_add_i, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[0,1]")    // swap(a + i b)
 UPX_PK2(swap_conj_add_i, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]")   // swap(conj a + i conj b)
 #undef UPX_PK2
+// g.x z - u with the halves of z (and of u) exchanged: the two spectra of mask() in one instruction each
+UPX_HD cf fma_swap_sub(cf z, cf g, cf u) {    // swap(g.x z - u) = (g.x z.y - u.y, g.x z.x - u.x)
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[0,0,0] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t) : "v"(z), "v"(g), "v"(u));
+    return t;
+}
+UPX_HD cf fma_swapz_sub(cf z, cf g, cf u) {   // swap(g.x z) - u = (g.x z.y - u.x, g.x z.x - u.y)
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t) : "v"(z), "v"(g), "v"(u));
+    return t;
+}
 #else
 UPX_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 UPX_HD cf add_mi(cf a, cf b) { return mk(a.x + b.y, a.y - b.x); }
@@ -94,6 +105,8 @@ UPX_HD cf add_conj(cf a, cf b) { return mk(a.x + b.x, a.y - b.y); }
 UPX_HD cf mi_sub_conj(cf a, cf b) { return mk(a.y + b.y, b.x - a.x); }
 UPX_HD cf swap_add_i(cf a, cf b) { return mk(a.y + b.x, a.x - b.y); }
 UPX_HD cf swap_conj_add_i(cf a, cf b) { return mk(b.x - a.y, a.x + b.y); }
+UPX_HD cf fma_swap_sub(cf z, cf g, cf u) { return mk(g.x * z.y - u.y, g.x * z.x - u.x); }
+UPX_HD cf fma_swapz_sub(cf z, cf g, cf u) { return mk(g.x * z.y - u.x, g.x * z.x - u.y); }
 #endif
 
 UPX_HD float fast_rcp(float v) {
@@ -134,6 +147,9 @@ UPX_HD const UPX_GLOBAL T* opaque(const T* p) {
 // constraints of volatile cost more than the pairing - 3.9 ms vs 2.75 ms for C3 - so plain loads stay.)
 UPX_HD cf lds_load(const cf* p) { return *p; }
 
+#if !defined(UPX_MASK_ALGEBRA)
+#define UPX_MASK_ALGEBRA 1   // single-band launches: mask() through mask_weight (0: the general per-band sum)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define UPX_DEVICE_PASS true
 #else
@@ -256,16 +272,100 @@ UPX_HD void dft4_mi2(cf& a0, cf& a1, cf& a2, cf& a3) {
 UPX_HD cf mul_w8_1(cf a) { return scale(add_mi(a, a), kSqrtHalf); }    // (x + y, y - x) / sqrt2
 UPX_HD cf mul_w8_3(cf a) { return scale(sub_mi(a, a), -kSqrtHalf); }   // -(x - y, y + x) / sqrt2
 
+// ---------------------------------------------------------------------------
+// Pruned butterflies.  A band's gain vector (center_extraction.py:334-351) is zero outside its pass band, so the
+// bins there carry nothing: the forward transform's last pass need not produce them and the inverse transform's
+// first pass sees zeros there.  Which register slots those are is known when the plan is created (Live<> below),
+// so the butterflies take two compile-time masks: IM bit i = input i may be non-zero, OM bit i = output i is
+// used.  An unused output's variable is left untouched; a dead input's variable is never read.  With both masks
+// full every helper is the plain butterfly above (same instructions, same order).
+// ---------------------------------------------------------------------------
+template <int I>
+struct IC {
+    static constexpr int value = I;
+};
+template <int B, int E, class F>
+UPX_HD void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+UPX_HD cf cneg(cf a) { return mk(-a.x, -a.y); }
+UPX_HD cf mul_pi(cf a) { return mk(-a.y, a.x); }   // a * (+i)
+template <bool LA, bool LB>
+UPX_HD cf padd(cf a, cf b) {   // a + b
+    if constexpr (LA && LB) return a + b;
+    else if constexpr (LA) return a;
+    else if constexpr (LB) return b;
+    else return mk(0.f, 0.f);
+}
+template <bool LA, bool LB>
+UPX_HD cf psub(cf a, cf b) {   // a - b
+    if constexpr (LA && LB) return a - b;
+    else if constexpr (LA) return a;
+    else if constexpr (LB) return cneg(b);
+    else return mk(0.f, 0.f);
+}
+template <bool LA, bool LB>
+UPX_HD cf padd_mi(cf a, cf b) {   // a - i b
+    if constexpr (LA && LB) return add_mi(a, b);
+    else if constexpr (LA) return a;
+    else if constexpr (LB) return mul_mi(b);
+    else return mk(0.f, 0.f);
+}
+template <bool LA, bool LB>
+UPX_HD cf psub_mi(cf a, cf b) {   // a + i b
+    if constexpr (LA && LB) return sub_mi(a, b);
+    else if constexpr (LA) return a;
+    else if constexpr (LB) return mul_pi(b);
+    else return mk(0.f, 0.f);
+}
+constexpr unsigned bit(unsigned m, int i) { return (m >> i) & 1u; }
+// MI2: input a2 is still to be multiplied by -i (dft4_mi2)
+template <unsigned IM, unsigned OM, bool MI2 = false>
+UPX_HD void dft4_p(cf& a0, cf& a1, cf& a2, cf& a3) {
+    if constexpr ((IM & 15u) == 15u && (OM & 15u) == 15u) {
+        if constexpr (MI2) dft4_mi2(a0, a1, a2, a3);
+        else dft4(a0, a1, a2, a3);
+    } else {
+        constexpr bool l0 = bit(IM, 0), l1 = bit(IM, 1), l2 = bit(IM, 2), l3 = bit(IM, 3);
+        constexpr bool le = l0 || l2, lo = l1 || l3;
+        cf t0 = mk(0.f, 0.f), t1 = t0, t2 = t0, d = t0;
+        if constexpr ((OM & 5u) != 0) {   // outputs 0, 2
+            t0 = MI2 ? padd_mi<l0, l2>(a0, a2) : padd<l0, l2>(a0, a2);
+            t2 = padd<l1, l3>(a1, a3);
+        }
+        if constexpr ((OM & 10u) != 0) {   // outputs 1, 3
+            t1 = MI2 ? psub_mi<l0, l2>(a0, a2) : psub<l0, l2>(a0, a2);
+            d = psub<l1, l3>(a1, a3);
+        }
+        if constexpr (bit(OM, 0)) a0 = padd<le, lo>(t0, t2);
+        if constexpr (bit(OM, 2)) a2 = psub<le, lo>(t0, t2);
+        if constexpr (bit(OM, 1)) a1 = padd_mi<le, lo>(t1, d);
+        if constexpr (bit(OM, 3)) a3 = psub_mi<le, lo>(t1, d);
+    }
+}
+
 template <int R>
 struct Dft;
 
 template <>
 struct Dft<2> {
     static UPX_HD void run(cf* v) { dft2(v[0], v[1]); }
+    template <unsigned IM, unsigned OM>
+    static UPX_HD void run_p(cf* v) {
+        constexpr bool l0 = bit(IM, 0), l1 = bit(IM, 1);
+        const cf a = v[0], b = v[1];
+        if constexpr (bit(OM, 0)) v[0] = padd<l0, l1>(a, b);
+        if constexpr (bit(OM, 1)) v[1] = psub<l0, l1>(a, b);
+    }
 };
 template <>
 struct Dft<4> {
     static UPX_HD void run(cf* v) { dft4(v[0], v[1], v[2], v[3]); }
+    template <unsigned IM, unsigned OM>
+    static UPX_HD void run_p(cf* v) { dft4_p<IM, OM>(v[0], v[1], v[2], v[3]); }
 };
 template <>
 struct Dft<8> {
@@ -281,6 +381,31 @@ struct Dft<8> {
         v[1] = e1 + o1; v[5] = e1 - o1;
         v[2] = add_mi(e2, o2); v[6] = sub_mi(e2, o2);   // o2 * (-i)
         v[3] = e3 + o3; v[7] = e3 - o3;
+    }
+    template <unsigned IM, unsigned OM>
+    static UPX_HD void run_p(cf* v) {
+        if constexpr ((IM & 255u) == 255u && (OM & 255u) == 255u) {
+            run(v);
+        } else {
+            constexpr unsigned ime = bit(IM, 0) | bit(IM, 2) << 1 | bit(IM, 4) << 2 | bit(IM, 6) << 3;
+            constexpr unsigned imo = bit(IM, 1) | bit(IM, 3) << 1 | bit(IM, 5) << 2 | bit(IM, 7) << 3;
+            constexpr unsigned om4 = (OM | OM >> 4) & 15u;   // e_k and o_k feed outputs k and k + 4
+            constexpr bool le = ime != 0, lo = imo != 0;
+            cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+            cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+            dft4_p<ime, om4>(e0, e1, e2, e3);
+            dft4_p<imo, om4>(o0, o1, o2, o3);
+            if constexpr (lo && bit(om4, 1)) o1 = mul_w8_1(o1);
+            if constexpr (lo && bit(om4, 3)) o3 = mul_w8_3(o3);
+            if constexpr (bit(OM, 0)) v[0] = padd<le, lo>(e0, o0);
+            if constexpr (bit(OM, 4)) v[4] = psub<le, lo>(e0, o0);
+            if constexpr (bit(OM, 1)) v[1] = padd<le, lo>(e1, o1);
+            if constexpr (bit(OM, 5)) v[5] = psub<le, lo>(e1, o1);
+            if constexpr (bit(OM, 2)) v[2] = padd_mi<le, lo>(e2, o2);
+            if constexpr (bit(OM, 6)) v[6] = psub_mi<le, lo>(e2, o2);
+            if constexpr (bit(OM, 3)) v[3] = padd<le, lo>(e3, o3);
+            if constexpr (bit(OM, 7)) v[7] = psub<le, lo>(e3, o3);
+        }
     }
 };
 template <>
@@ -307,6 +432,46 @@ struct Dft<16> {
             if (k1 == 2) dft4_mi2(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
             else dft4(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
             v[k1] = y[0][k1]; v[k1 + 4] = y[1][k1]; v[k1 + 8] = y[2][k1]; v[k1 + 12] = y[3][k1];
+        }
+    }
+    // inputs 4a + b with mask bit set may be non-zero, outputs k1 + 4 k2 with mask bit set are used
+    static constexpr unsigned col4(unsigned m, int b) { return bit(m, b) | bit(m, 4 + b) << 1 | bit(m, 8 + b) << 2 | bit(m, 12 + b) << 3; }
+    template <unsigned IM, unsigned OM>
+    static UPX_HD void run_p(cf* v) {
+        if constexpr ((IM & 0xFFFFu) == 0xFFFFu && (OM & 0xFFFFu) == 0xFFFFu) {
+            run(v);
+        } else {
+            // first stage: column b is live if any of its inputs is; its output k1 is used if any output k1 + 4 k2 is
+            constexpr unsigned om1 = (col4(OM, 0) ? 1u : 0u) | (col4(OM, 1) ? 2u : 0u) | (col4(OM, 2) ? 4u : 0u) | (col4(OM, 3) ? 8u : 0u);
+            constexpr unsigned ly = (col4(IM, 0) ? 1u : 0u) | (col4(IM, 1) ? 2u : 0u) | (col4(IM, 2) ? 4u : 0u) | (col4(IM, 3) ? 8u : 0u);
+            cf y[4][4] = {};   // (dead columns stay zero and are never read)
+            static_for<0, 4>([&](auto ib) {
+                constexpr int b = decltype(ib)::value;
+                if constexpr (bit(ly, b)) {
+                    y[b][0] = v[b]; y[b][1] = v[4 + b]; y[b][2] = v[8 + b]; y[b][3] = v[12 + b];
+                    dft4_p<col4(IM, b), om1>(y[b][0], y[b][1], y[b][2], y[b][3]);
+                }
+            });
+            const cf w1 = mk(kC16, -kS16), w3 = mk(kS16, -kC16);
+            if constexpr (bit(ly, 1) && bit(om1, 1)) y[1][1] = cmul(y[1][1], w1);
+            if constexpr (bit(ly, 1) && bit(om1, 2)) y[1][2] = mul_w8_1(y[1][2]);
+            if constexpr (bit(ly, 1) && bit(om1, 3)) y[1][3] = cmul(y[1][3], w3);
+            if constexpr (bit(ly, 2) && bit(om1, 1)) y[2][1] = mul_w8_1(y[2][1]);
+            if constexpr (bit(ly, 2) && bit(om1, 3)) y[2][3] = mul_w8_3(y[2][3]);   // y[2][2] * (-i): dft4_p<.., MI2>
+            if constexpr (bit(ly, 3) && bit(om1, 1)) y[3][1] = cmul(y[3][1], w3);
+            if constexpr (bit(ly, 3) && bit(om1, 2)) y[3][2] = mul_w8_3(y[3][2]);
+            if constexpr (bit(ly, 3) && bit(om1, 3)) y[3][3] = cmul(y[3][3], mk(-kC16, kS16));
+            static_for<0, 4>([&](auto ik) {
+                constexpr int k1 = decltype(ik)::value;
+                constexpr unsigned om2 = bit(OM, k1) | bit(OM, k1 + 4) << 1 | bit(OM, k1 + 8) << 2 | bit(OM, k1 + 12) << 3;
+                if constexpr (om2 != 0) {
+                    dft4_p<ly, om2, k1 == 2>(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
+                    if constexpr (bit(om2, 0)) v[k1] = y[0][k1];
+                    if constexpr (bit(om2, 1)) v[k1 + 4] = y[1][k1];
+                    if constexpr (bit(om2, 2)) v[k1 + 8] = y[2][k1];
+                    if constexpr (bit(om2, 3)) v[k1 + 12] = y[3][k1];
+                }
+            });
         }
     }
 };
@@ -467,6 +632,19 @@ UPX_HD void mask_bin(cf l, cf r, cf& c, cf& ls, cf& rs) {
     rs = r - c;
 }
 
+// The same mask as one weight for a launch that carries ONE band: with l = g2 l0, r = g2 r0 (g2 = gain / 2 >= 0)
+//   C = w (l0 + r0),  w = g2 * 0.5 coh (1 - |bal|),   Ls + i Rs = 2 g2 Z[k] - (1 + i) C   (because l0 + i r0 = 2 Z[k]),
+// so the two inverse-transform inputs of a bin pair need C only (band_program's mask()).  coh (1 - |bal|) =
+// p (S - |D|) / ((p + eps) S) with p = |l||r|, S = |l| + |r| + eps, D = |l| - |r|: one reciprocal.  g2 = 0 gives w = 0.
+UPX_HD float mask_weight(cf l0, cf r0, float g2) {
+    const float ml = g2 * fast_sqrt(l0.x * l0.x + l0.y * l0.y);
+    const float mr = g2 * fast_sqrt(r0.x * r0.x + r0.y * r0.y);
+    const float p = ml * mr;
+    const float sum = ml + mr + kEps;
+    const float num = (0.5f * g2) * p * (sum - __builtin_fabsf(ml - mr));
+    return num * fast_rcp((p + kEps) * sum);
+}
+
 // Per-thread state kept in registers across frames.
 template <int P>
 struct ThreadT {
@@ -493,26 +671,61 @@ struct Stream {
     // W_(NS*R)^(r*k), k = j mod NS (j = lane + q LANES), then a radix-R DFT in place;
     // output r belongs at (j - k) R + k + r NS.  Twiddles come from the LDS table
     // tw[row(PI, r)][k] (compact: NS entries per row).
-    template <int PI>
+    // IM / OM: bit s = slot s may be non-zero on entry / is used on exit (pruned butterflies; full masks = plain pass)
+    static constexpr unsigned FULL = (1u << P) - 1u;
+    template <int PI, unsigned IM = FULL, unsigned OM = FULL>
     static UPX_HD void pass_compute(Thread& th, const cf* tw, int lane) {
         constexpr int R = PS::r[PI];
         constexpr int NS = pass_ns(PS::r, PI);
         constexpr int NB = P / R;
         constexpr int OFF = tw_offset(PS::r, PI);
+        if constexpr ((IM & FULL) == FULL && (OM & FULL) == FULL) {
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            cf v[R];
+            for (int q = 0; q < NB; ++q) {
+                cf v[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = th.x[q + r * NB];
-            if (NS > 1) {
-                const cf* row = tw + OFF + ((lane + q * LANES) & (NS - 1));
+                for (int r = 0; r < R; ++r) v[r] = th.x[q + r * NB];
+                if (NS > 1) {
+                    const cf* row = tw + OFF + ((lane + q * LANES) & (NS - 1));
 #pragma unroll
-                for (int r = 1; r < R; ++r) v[r] = cmul(v[r], lds_load(row + (r - 1) * NS));
+                    for (int r = 1; r < R; ++r) v[r] = cmul(v[r], lds_load(row + (r - 1) * NS));
+                }
+                Dft<R>::run(v);
+#pragma unroll
+                for (int r = 0; r < R; ++r) th.x[q + r * NB] = v[r];
             }
-            Dft<R>::run(v);
-#pragma unroll
-            for (int r = 0; r < R; ++r) th.x[q + r * NB] = v[r];
+        } else {
+            static_for<0, NB>([&](auto iq) {
+                constexpr int q = decltype(iq)::value;
+                constexpr unsigned im = gather_mask(IM, q, NB, R), om = gather_mask(OM, q, NB, R);
+                if constexpr (om != 0) {
+                    cf v[R] = {}, w[R] = {};
+                    const cf* row = tw + OFF + ((lane + q * LANES) & (NS - 1));
+                    static_for<1, R>([&](auto ir) {   // every twiddle read before the first multiply (read_compute)
+                        constexpr int r = decltype(ir)::value;
+                        if constexpr (NS > 1 && bit(im, r)) w[r] = lds_load(row + (r - 1) * NS);
+                    });
+                    static_for<0, R>([&](auto ir) {
+                        constexpr int r = decltype(ir)::value;
+                        if constexpr (bit(im, r)) {
+                            v[r] = th.x[q + r * NB];
+                            if constexpr (NS > 1 && r > 0) v[r] = cmul(v[r], w[r]);
+                        }
+                    });
+                    Dft<R>::template run_p<im, om>(v);
+                    static_for<0, R>([&](auto ir) {
+                        constexpr int r = decltype(ir)::value;
+                        if constexpr (bit(om, r)) th.x[q + r * NB] = v[r];
+                    });
+                }
+            });
         }
+    }
+    // bits q + r NB (r < R) of a slot mask, as the mask of butterfly q
+    static constexpr unsigned gather_mask(unsigned m, int q, int nb, int r_n) {
+        unsigned o = 0;
+        for (int r = 0; r < r_n; ++r) o |= bit(m, q + r * nb) << r;
+        return o;
     }
     // scatter of a radix-P pass (one butterfly per lane): slot r -> (lane - k) P + k + r NS
     template <int PI>
@@ -528,10 +741,12 @@ struct Stream {
 #pragma unroll
         for (int r = 0; r < R; ++r) b[r * STEP] = th.x[r];
     }
+    template <unsigned IM = FULL>
     static UPX_HD void read_all(Thread& th, const cf* lds, int lane) {
         const cf* b = lds + padp<P>(lane);
 #pragma unroll
-        for (int s = 0; s < P; ++s) th.x[s] = lds_load(b + s * C::SPITCH);
+        for (int s = 0; s < P; ++s)
+            if (bit(IM, s)) th.x[s] = lds_load(b + s * C::SPITCH);
     }
     // Register form of pass_write<n-2> + read_all for streams of ROWS = LANES/16 rows (Cfg::SWAP_LAST): output r = ROWS h + c
     // of the lane in row a belongs in slot ROWS^2... = (16/ROWS) a + h of the same column in row c - per h a ROWS x ROWS
@@ -580,11 +795,14 @@ struct Stream {
     // 12): left to itself the scheduler splits them into three batches and waits for each to come back in
     // full - three exposed LDS round trips per pass instead of one.
     // (EAGER = false where registers are scarce: the tail phases hold windows, old samples and the next frame.)
-    template <int PI, bool EAGER = true>
+    template <int PI, bool EAGER = true, unsigned IM = FULL, unsigned OM = FULL>
     static UPX_HD void read_compute(Thread& th, const cf* lds, const cf* tw, int lane) {
         constexpr int R = PS::r[PI];
         constexpr int NS = pass_ns(PS::r, PI);
-        if constexpr (R == P && P == 16 && EAGER) {
+        if constexpr ((IM & FULL) != FULL || (OM & FULL) != FULL) {
+            read_all<IM>(th, lds, lane);
+            pass_compute<PI, IM, OM>(th, tw, lane);
+        } else if constexpr (R == P && P == 16 && EAGER) {
             constexpr int OFF = tw_offset(PS::r, PI);
             const cf* b = lds + padp<P>(lane);
             const cf* row = tw + OFF + (lane & (NS - 1));
@@ -612,10 +830,10 @@ struct Stream {
 
     // passes PI..n-2:  [read, transform] | [scatter] |   ('|' = barrier)
     // the last pass after mid_passes<1, SWAP>
-    template <bool SWAP, bool EAGER = true>
+    template <bool SWAP, bool EAGER = true, unsigned OM = FULL>
     static UPX_HD void last_compute(Thread& th, const cf* lds, const cf* tw, int lane) {
-        if constexpr (SWAP) pass_compute<PS::n - 1>(th, tw, lane);   // the inputs are in the registers already
-        else read_compute<PS::n - 1, EAGER>(th, lds, tw, lane);
+        if constexpr (SWAP) pass_compute<PS::n - 1, FULL, OM>(th, tw, lane);   // the inputs are in the registers already
+        else read_compute<PS::n - 1, EAGER, FULL, OM>(th, lds, tw, lane);
     }
     // SWAP (only with C::SWAP_LAST): the exchange in front of the last pass stays in registers; the caller ends the
     // transform with last_compute<true>
@@ -671,7 +889,19 @@ struct Stream {
 // workgroups of a launch are interior.  Their loop body has no branch: every load and store is unconditional, so
 // the backend counts outstanding vector-memory operations exactly (`s_waitcnt vmcnt(n)` leaves the younger prefetches
 // and stores in flight); where paths with different numbers of loads or stores merge it has to wait with vmcnt(0).
-template <class C, class Ex, bool MERGED = true, bool IN = false, bool ACC = false>
+//
+// LV = Live<S0, S1> (single-band launches of plain streams): only the own-bin slots S0 <= s < S1 - bins lane + s LANES -
+// carry gain anywhere in the launch (the host reads that off the gain vector when the plan is created; S1 >= P/2 also
+// means "the Nyquist bin may carry gain").  The forward transform's last pass then produces only those slots and
+// their mirror partners, the L/R split, mask, partner parking and mirror writes run over them alone, and the first
+// pass of the inverse transforms knows the other inputs to be zero (pruned butterflies, Dft<>::run_p).  S0 <= 1.
+template <int S0_, int S1_>
+struct Live {
+    static constexpr int S0 = S0_, S1 = S1_;
+};
+using LiveAll = Live<0, 1 << 20>;
+
+template <class C, class Ex, bool MERGED = true, bool IN = false, bool ACC = false, class LV = LiveAll>
 UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     using SC = typename C::Sub;     // the FFT that goes through LDS: the frame itself, or a wide stream's sub-FFT
     using S = Stream<SC>;
@@ -686,6 +916,19 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     constexpr bool WIDE = C::WIDE;
     constexpr bool GAINS_EARLY = C::EARLY_LOADS && !MERGED;   // (the merged flavour also holds the second gain slot)
     constexpr bool SWAP = SC::SWAP_LAST;   // the exchange before the last pass stays in registers (device, 2- or 4-row streams)
+    // live own-bin slots [S0, S1); slots LO .. HI-1 are the ones whose mirror cells the mask (re)writes: one dead slot on
+    // either side, because lane 0's mirror of slot s lives in upper slot P - s and every other lane's in P - 1 - s
+    constexpr int S0 = LV::S0 < H ? LV::S0 : H, S1 = LV::S1 < H ? LV::S1 : H;
+    constexpr bool PRUNED = S0 > 0 || S1 < H;
+    constexpr bool NYQ = S1 == H;                                  // the Nyquist bin may carry gain
+    constexpr int LO = S0 > 0 ? S0 - 1 : 0, HI = S1 < H ? S1 + 1 : H;
+    constexpr int ULO = P - S1, UHI = P - S0 < P - 1 ? P - S0 : P - 1;   // upper slots that may be non-zero: [ULO, UHI]
+    constexpr unsigned FULLM = (1u << P) - 1u;
+    constexpr unsigned OWN_M = ((1u << S1) - 1u) & ~((1u << S0) - 1u);
+    constexpr unsigned UP_M = ((UHI >= P - 1 ? FULLM : ((1u << (UHI + 1)) - 1u)) & ~((1u << ULO) - 1u)) & FULLM;
+    constexpr unsigned LIVE_M = PRUNED ? (OWN_M | UP_M) : FULLM;
+    static_assert(!PRUNED || (!WIDE && !MERGED && S0 <= 1 && S0 < S1), "pruned flavours: plain streams, one band, S0 <= 1");
+    auto own_live = [](int s) { return s >= S0 && s < S1; };
 
     // A stream transforms the F frames [m0, m0+F), m0 = m_lo - 1 + stream * F, and nothing else: no halo
     // frames are recomputed.  Frames come in pairs (a, b) = (odd j, j+1) so that one inverse FFT returns the
@@ -821,8 +1064,9 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             // first gain slot of the mask three phases on: in front of the prefetch (an HBM miss), not behind it
             const UPX_GLOBAL float* gain = opaque(a.gain);
 #pragma unroll
-            for (int s = 0; s < H; ++s) th.g0[s] = gat(gain, (unsigned)lane, s * LANES);
-            th.gn[0] = gain[N / 2];
+            for (int s = 0; s < H; ++s)
+                if (own_live(s)) th.g0[s] = gat(gain, (unsigned)lane, s * LANES);
+            if constexpr (NYQ) th.gn[0] = gain[N / 2];
         }
         prefetch(tid, th, it + (half == 1 ? 1 : 0), half == 1 ? 0 : 1);
     };
@@ -1006,7 +1250,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         cf nyq_y = mk(0.f, 0.f);
         float nyq_c = 0.f;
         const int n_gain = MERGED ? a.n_gain : 1, gstride = a.gain_stride;
-        if (mir.first) {
+        if (NYQ && mir.first) {
             // Nyquist bin is real: L = Re Z[N/2], R = Im Z[N/2]
             const cf z = th.x[H];
             cf cn = mk(0.f, 0.f), lsn = cn, rsn = cn;
@@ -1025,15 +1269,30 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         // as far as the compiler can tell, so it would not hoist the reads itself)
         cf zpart[H];
 #pragma unroll
-        for (int s = 0; s < H; ++s) zpart[s] = lds_load(mir.zpart + (H - 1 - s) * SP);   // k == 0: spare row, unused
+        for (int s = 0; s < H; ++s)
+            if (own_live(s)) zpart[s] = lds_load(mir.zpart + (H - 1 - s) * SP);   // k == 0: spare row, unused
 #pragma unroll
         for (int s = 0; s < H; ++s) {
+            if (s < LO || s >= HI) continue;       // (pruned flavours) nothing of this slot is read again
+            const bool live = own_live(s);         // a dead slot next to the live ones: zeros into its mirror cell
             const bool dc = s == 0 && mir.first;   // k == 0
+            cf c = mk(0.f, 0.f), ls = c, rs = c;
+            cf yk = c, ym = c;                     // swap(Y[k]), swap(Y[N-k]): the inverse transform's input (iFFT by swap)
+            if (live) {
             const cf za = th.x[s];
             const cf zb = dc ? za : zpart[s];        // DC pairs with itself
             const cf l0 = add_conj(za, zb);      // Z[k] + conj Z[N-k]        (x gain/2 = L)
             const cf r0 = mi_sub_conj(za, zb);   // (Z[k] - conj Z[N-k]) / i  (x gain/2 = R)
-            cf c = mk(0.f, 0.f), ls = c, rs = c;
+            if constexpr (!MERGED && UPX_MASK_ALGEBRA) {
+                // one band: Y[k] = G Z[k] - (1 + i) C, Y[N-k] = G Z[N-k] - (1 + i) conj C, G = 2 g2 (mask_weight);
+                // no branch on the gain: a zero gain gives exact zeros, and the bins' latency chains interleave
+                const float g2 = th.g0[s];
+                c = scale(l0 + r0, mask_weight(l0, r0, g2));
+                const cf u = sub_mi(c, c);           // (1 + i) C; its swap is (1 + i) conj C
+                const cf gg = mk(g2 + g2, g2 + g2);
+                yk = fma_swap_sub(za, gg, u);
+                ym = fma_swapz_sub(zb, gg, u);
+            } else {
             auto add_band = [&](float g2) {
                 if (g2 != 0.f) {   // whole waves lie outside the band: the branch skips them
                     cf l = scale(l0, g2), r = scale(r0, g2), cq, lq, rq;
@@ -1053,8 +1312,11 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
                 }
             }
             // Y[k] = Ls + i Rs, Y[N-k] = conj(Ls) + i conj(Rs); kept re/im swapped (iFFT by swap)
-            th.x[s] = swap_add_i(ls, rs);
-            const cf ym = swap_conj_add_i(ls, rs);
+            yk = swap_add_i(ls, rs);
+            ym = swap_conj_add_i(ls, rs);
+            }
+            }
+            if (live) th.x[s] = yk;
             if (s == 0) {
                 cf* dst = mir.first ? mir.nyq : mir.ymir + (H - 1) * SP;
                 *dst = mir.first ? cswap(nyq_y) : ym;
@@ -1062,6 +1324,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
                 mir.ymir[(H - 1 - s) * SP] = ym;
             }
             // centre spectrum; the first lane's slot 0 packs the two real bins (DC, Nyquist)
+            if (!live && s > 0) continue;          // (a dead slot 0 still carries the Nyquist bin of the centre)
             const cf cv = dc ? mk(c.x, nyq_c) : c;
             if (half == 0) {
                 th.cs[s] = cv;
@@ -1084,8 +1347,9 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const int sl = tid % SL;
         const cf* b = lds_all + (tid / SL) * BUF + padp<P>(sl);
 #pragma unroll
-        for (int s = H; s < P; ++s) th.x[s] = lds_load(b + (WIDE ? s : s - H) * SP);
-        S::template pass_compute<0>(th, tw, sl);
+        for (int s = H; s < P; ++s)
+            if (bit(LIVE_M, s)) th.x[s] = lds_load(b + (WIDE ? s : s - H) * SP);
+        S::template pass_compute<0, LIVE_M>(th, tw, sl);
     };
     auto scatter0 = [&](int tid, Thread& th) { S::template pass_write<0>(th, lds_all + (tid / SL) * BUF, tid % SL); };
     auto mids = [&]() { S::template mid_passes<1, SWAP>(ex, lds_all, tw); };
@@ -1093,8 +1357,9 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         const UPX_GLOBAL float* gain = opaque(a.gain);   // (slot 0: head())
         if constexpr (!GAINS_EARLY) {
 #pragma unroll
-            for (int s = 0; s < H; ++s) th.g0[s] = gat(gain, (unsigned)(tid % LANES), s * LANES);
-            th.gn[0] = gain[N / 2];
+            for (int s = 0; s < H; ++s)
+                if (own_live(s)) th.g0[s] = gat(gain, (unsigned)(tid % LANES), s * LANES);
+            if constexpr (NYQ) th.gn[0] = gain[N / 2];
         }
         if constexpr (MERGED) {
             th.gn[1] = a.n_gain > 1 ? gain[a.gain_stride + N / 2] : 0.f;
@@ -1106,23 +1371,26 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
                 for (int s = 0; s < H; ++s) th.g1[s] = gat(gain + a.gain_stride, (unsigned)(tid % LANES), s * LANES);
             }
         }
-        S::template last_compute<SWAP>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
+        S::template last_compute<SWAP, true, LIVE_M>(th, lds_all + (tid / SL) * BUF, tw, tid % SL);
     };
     auto zsplit_write = [&](int tid, Thread& th) {
         cf* b = lds_all + (tid / SL) * BUF + padp<P>(tid % SL);
 #pragma unroll
-        for (int s = H; s < P; ++s) b[s * SP] = th.x[s];
+        for (int s = H; s < P; ++s)
+            if (bit(LIVE_M, s)) b[s * SP] = th.x[s];
     };
     auto stage_c = [&](int tid, Thread& th) {
         const Mirror mir = mirror_of(tid);
 #pragma unroll
         for (int s = 0; s < H; ++s) {
-            th.x[s] = th.cs[s];
+            if (s < LO || s >= HI) continue;
+            const bool live = own_live(s);
+            if (live) th.x[s] = th.cs[s];
             if (s == 0) {
                 cf* dst = mir.first ? mir.nyq : mir.ymir + (H - 1) * SP;
                 *dst = th.part[0];
             } else {
-                mir.ymir[(H - 1 - s) * SP] = th.part[s];
+                mir.ymir[(H - 1 - s) * SP] = live ? th.part[s] : mk(0.f, 0.f);
             }
         }
     };
@@ -1278,13 +1546,13 @@ UPX_HD bool band_interior(const BandArgs& a, int wg_index) {
     return first >= (lo > 0 ? lo : 0) && end <= hi && end * C::HOP <= a.t_out && (end + 1) * C::HOP + C::N <= a.t_in;
 }
 // band_program with the interior flavour where it applies (the choice is uniform over the workgroup)
-template <class C, class Ex, bool MERGED = true>
+template <class C, class Ex, bool MERGED = true, class LV = LiveAll>
 UPX_HD void band_program_auto(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     if (band_interior<C>(a, wg_index)) {
-        if (a.accumulate) band_program<C, Ex, MERGED, true, true>(ex, a, lds_all, wg_index);
-        else band_program<C, Ex, MERGED, true, false>(ex, a, lds_all, wg_index);
+        if (a.accumulate) band_program<C, Ex, MERGED, true, true, LV>(ex, a, lds_all, wg_index);
+        else band_program<C, Ex, MERGED, true, false, LV>(ex, a, lds_all, wg_index);
     } else {
-        band_program<C, Ex, MERGED, false, false>(ex, a, lds_all, wg_index);
+        band_program<C, Ex, MERGED, false, false, LV>(ex, a, lds_all, wg_index);
     }
 }
 

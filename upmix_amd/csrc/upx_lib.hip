@@ -104,7 +104,8 @@ struct DevExec {
 
 // WPE = waves per SIMD the register allocator must leave room for (2 -> 256 VGPRs, 3 -> 168).
 // MERGED = false: the launch carries one band (one gain slot per bin): the flavour single bands get.
-template <class C, int WPE, bool MERGED = true>
+// LV = upx::Live<S0, S1>: single-band flavour specialised for the own-bin slots that carry gain (upx_core.h).
+template <class C, int WPE, bool MERGED = true, class LV = upx::LiveAll>
 __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Ex = DevExec<C::WAVE_SYNC || C::WIDE, C::P>;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     // the interior flavour (two more instantiations of the program) for the kernels plans select by default; the
     // 8-points-per-lane and plain-schedule alternates (UPX_KERNEL_VARIANT) keep the one general body
     if constexpr (C::P == 16 && (C::WIDE || C::LOG2N <= 11))
-        upx::band_program_auto<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+        upx::band_program_auto<C, Ex, MERGED, LV>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
     else
         upx::band_program<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
@@ -123,13 +124,19 @@ __global__ void upx_stream_seam_add_kernel(upx::BandArgs a, int n_streams, int t
         upx::stream_seam_add(a, n_streams, tail, hop, g);
 }
 
+// max |x| as a bit pattern: non-negative floats order like their bit patterns, and a NaN (sign cleared) lies above
+// every number, so a NaN anywhere gives NaN - what np.max(np.abs(.)) gives main.py:53, :85-88
 __global__ void upx_absmax_kernel(const float* x, long long n, unsigned int* result) {
-    float m = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(x[i]));
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    // non-negative floats order like their bit patterns
-    if ((threadIdx.x & 63) == 0) atomicMax(result, __float_as_uint(m));
+    unsigned int m = 0u;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned int b = __float_as_uint(x[i]) & 0x7fffffffu;
+        m = b > m ? b : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int q = (unsigned int)__shfl_xor((int)m, o);
+        m = q > m ? q : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(result, m);
 }
 
 __global__ void upx_scale_kernel(float* x, long long n, float s) {
@@ -419,14 +426,14 @@ const BigEntry* find_big(int log2n) {
     return it == table.end() ? nullptr : &it->second;
 }
 
-template <class C, int WPE, bool MERGED = true>
+template <class C, int WPE, bool MERGED = true, class LV = upx::LiveAll>
 struct Entry {
     static constexpr int kLds = C::LDS_CF * (int)sizeof(upx::cf);
     static void launch(const upx::BandArgs& a, int n_wg, hipStream_t st) {
-        hipLaunchKernelGGL((upx_band_kernel<C, WPE, MERGED>), dim3(n_wg), dim3(C::WG), kLds, st, a);
+        hipLaunchKernelGGL((upx_band_kernel<C, WPE, MERGED, LV>), dim3(n_wg), dim3(C::WG), kLds, st, a);
     }
     static int prepare() {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_band_kernel<C, WPE, MERGED>),
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_band_kernel<C, WPE, MERGED, LV>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     }
     static void fill(upx::cf* tw) { upx::fill_tables<C>(tw, turn_trig); }
@@ -466,6 +473,16 @@ const KernelEntry* find_kernel(int log2n, int k, int variant) {
         UPX_REG1_WIDE(12, 2) UPX_REG1_WIDE(12, 4) UPX_REG1_WIDE(12, 8) UPX_REG1_WIDE(13, 2) UPX_REG1_WIDE(13, 4) UPX_REG1_WIDE(13, 8)
 #undef UPX_REG1_WIDE
 #undef UPX_REG1
+        // variant 100 + 10 S0 + S1 = variant 10 specialised for the live own-bin slots [S0, S1) (upx::Live; hop N/4).
+        // The reference's planner ties N to the band's low edge, so a middle band covers bins 31..205 whatever its N
+        // (slots 0..3 at N = 1024, 0..1 at N = 2048) and a top band everything from bin 31 up (slots 1..7 at N = 256).
+#define UPX_REGL(L, A, B)                                                                             \
+    t[std::make_tuple(L, 4, 100 + 10 * A + B)] = Entry<upx::Cfg<L, 4, 16>, 2, false, upx::Live<A, B>>::get( \
+        "upx_band_kernel<upx::Cfg<" #L ", 4, 16>, 2, false, upx::Live<" #A ", " #B ">>");
+        // (Live<1, 8> - a top band, everything but slot 0 - was measured slower than the general flavour at N = 256:
+        // 0.395 vs 0.388 ms, one slot in eight pruned against the eager read order of the last forward pass lost)
+        UPX_REGL(10, 0, 2) UPX_REGL(10, 0, 3) UPX_REGL(10, 0, 4) UPX_REGL(11, 0, 2) UPX_REGL(11, 0, 3) UPX_REGL(11, 0, 4)
+#undef UPX_REGL
         UPX_REG_SIZES(2, 8, 4, 1) UPX_REG_SIZES(4, 8, 4, 1) UPX_REG_SIZES(8, 8, 4, 1)
         UPX_REG_SIZES(2, 16, 2, 2) UPX_REG_SIZES(4, 16, 2, 2) UPX_REG_SIZES(8, 16, 2, 2)
 #undef UPX_REG_WIDE
@@ -475,6 +492,7 @@ const KernelEntry* find_kernel(int log2n, int k, int variant) {
         return t;
     }();
     auto it = table.find(std::make_tuple(log2n, k, variant));
+    if (it == table.end() && variant >= 100) return nullptr;   // live-slot flavours: the caller tries the next wider one
     if (it == table.end() && variant != 0) it = table.find(std::make_tuple(log2n, k, 0));
     return it == table.end() ? nullptr : &it->second;
 }
@@ -529,6 +547,11 @@ struct upx_plan {
     long long timed_calls = 0;      // timed upx_process_device calls since timing was enabled
     unsigned int* d_scalar = nullptr;
     float pipe_ms[3] = {0.f, 0.f, 0.f};
+    // tuning knobs, read from the environment ONCE when the plan is created (buffers are sized from them)
+    long long knob_zoom_scratch_mb = 192;   // UPX_ZOOM_SCRATCH_MB: spectra between the two band-limited kernels
+    double knob_zoom_fill = 2.0;            // UPX_ZOOM_FILL: synthesis streams per resident workgroup slot
+    long long knob_zoom_f = 0;              // UPX_ZOOM_F: frames per synthesis stream (0 = automatic)
+    long long knob_stream_chunk = 1LL << 22;   // UPX_STREAM_CHUNK: owned samples per chunk of a streamed host call
     float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
     size_t seam_floats = 0;
     upx::cf* d_scratch = nullptr;   // z | y | yc of the big path (shared by all big bands)
@@ -544,6 +567,11 @@ struct upx_plan {
     // device buffers of upx_wav_pipeline, kept between calls (grow only): pcm in, stereo, planes, 3 outputs
     void* d_wav[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t wav_cap[6] = {0, 0, 0, 0, 0, 0};
+    // the shard between upx_wav_shard_begin and upx_wav_shard_finish
+    bool wav_open = false;
+    int64_t wav_tin = 0, wav_own = 0, wav_tout = 0;
+    int wav_fmt = 0, wav_ch = 0;
+    hipEvent_t wav_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct upx_comm {
@@ -600,9 +628,8 @@ int load_rccl() {
 // frames of spectra the scratch between analysis and synthesis holds (a launch pair covers at most this many):
 // 128 MB of y + 64 MB of yc (inside the 256 MB Infinity Cache; 10 min at 48 kHz is one launch pair for every band
 // with D >= 16, and short launch pairs cost more in tails than a smaller scratch saves)
-int zoom_frames_cap(int zp) {
-    const char* env = std::getenv("UPX_ZOOM_SCRATCH_MB");
-    const long long mb = env ? std::atoll(env) : 192;
+int zoom_frames_cap(const upx_plan* p, int zp) {
+    const long long mb = p->knob_zoom_scratch_mb;
     long long frames = mb * (1 << 20) / ((long long)zp * 12);   // P complex per frame + P/2 per frame for the pairs
     if (frames < 64) frames = 64;
     return (int)(frames & ~1LL);
@@ -618,8 +645,7 @@ int zoom_resident(const BandState& s, bool analysis = false) {
 // streams the synthesis aims for: about UPX_ZOOM_FILL x the chip's workgroup slots, an Ls/Rs workgroup counting
 // 1 and a centre workgroup 1/2 per (stream, residue group)
 long long zoom_streams_wanted(const upx_plan* p, const BandState& s) {
-    const char* env = std::getenv("UPX_ZOOM_FILL");
-    const double fill = env ? std::atof(env) : 2.0;
+    const double fill = p->knob_zoom_fill;
     const int groups = s.zoom_d / s.zoom->rg;
     long long want = (long long)(fill * p->n_cu * zoom_resident(s) / (1.5 * groups));
     return want < 1 ? 1 : want;
@@ -691,6 +717,10 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     } guard{new upx_plan()};
     upx_plan* p = guard.p;
     p->device = device;
+    if (const char* e = std::getenv("UPX_ZOOM_SCRATCH_MB")) p->knob_zoom_scratch_mb = std::atoll(e);
+    if (const char* e = std::getenv("UPX_ZOOM_FILL")) p->knob_zoom_fill = std::atof(e);
+    if (const char* e = std::getenv("UPX_ZOOM_F")) p->knob_zoom_f = std::atoll(e);
+    if (const char* e = std::getenv("UPX_STREAM_CHUNK")) p->knob_stream_chunk = std::atoll(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         p->n_cu = prop.multiProcessorCount;
@@ -816,7 +846,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             HIP_TRY(hipMalloc(&s.d_ramp, host.size() * sizeof(upx::cf)));
             HIP_TRY(hipMemcpy(s.d_ramp, host.data(), host.size() * sizeof(upx::cf), hipMemcpyHostToDevice));
             // spectra between the two kernels: kZoomFrames frames of P complex (+ half as many pairs)
-            const size_t need = (size_t)zoom_frames_cap(s.zoom_p) * s.zoom_p * 3 / 2;
+            const size_t need = (size_t)zoom_frames_cap(p, s.zoom_p) * s.zoom_p * 3 / 2;
             if (need > p->zoom_cf) p->zoom_cf = need;
         }
         if (s.big) {
@@ -863,6 +893,21 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             // N = 4096 loses 3 % (its few spills sit on the signal-edge path only), so it keeps the general flavour.
             const KernelEntry* one = find_kernel(s.log2n, s.n / s.hop, 10);
             if (one && one->layout == s.kern->layout) {
+                // ... and, where one is built, the flavour specialised for the own-bin slots that carry gain: slot s of
+                // a lane holds bin lane + s lanes (s < 8); the smallest instantiated range [S0, S1) that covers them,
+                // S1 = 8 whenever the Nyquist bin carries gain
+                if (!std::getenv("UPX_NO_LIVE_FLAVOUR") && s.k == 4) {
+                    int lo = 8, hi = 0;
+                    for (int sl = 0; sl < 8; ++sl)
+                        for (int i = sl * one->lanes; i < (sl + 1) * one->lanes; ++i)
+                            if (table[(size_t)i] != 0.f) { lo = sl < lo ? sl : lo; hi = sl + 1; break; }
+                    if (table[(size_t)nb - 1] != 0.f) hi = 8;
+                    const KernelEntry* live = nullptr;
+                    for (int b1 = hi; b1 <= 8 && !live && lo < hi; ++b1)
+                        for (int a0 = lo > 1 ? 1 : lo; a0 >= 0 && !live; --a0)
+                            if (a0 > 0 || b1 < 8) live = find_kernel(s.log2n, 4, 100 + 10 * a0 + b1);
+                    if (live && live->layout == s.kern->layout) one = live;
+                }
                 if (int e = one->prepare())
                     return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
                 s.kern = one;
@@ -912,6 +957,7 @@ void upx_plan_destroy(upx_plan* p) {
         if (p->ev_comp[i]) (void)hipEventDestroy(p->ev_comp[i]);
     }
     for (auto* q : p->d_wav) if (q) (void)hipFree(q);
+    for (auto e : p->wav_ev) if (e) (void)hipEventDestroy(e);
     if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
     if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -937,6 +983,20 @@ int upx_dev_free(upx_plan* p, void* ptr) {
     if (!p) return fail(UPX_ERR_INVALID, "upx_dev_free: NULL plan");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipFree(ptr));
+    return UPX_OK;
+}
+// page-locked host memory: copies to and from it go over the link without a staging copy and without page faults
+int upx_host_alloc(upx_plan* p, void** ptr, size_t bytes) {
+    if (!p || !ptr) return fail(UPX_ERR_INVALID, "upx_host_alloc: NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 4, hipHostMallocPortable);
+    if (e != hipSuccess) return fail(UPX_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return UPX_OK;
+}
+int upx_host_free(upx_plan* p, void* ptr) {
+    if (!p) return fail(UPX_ERR_INVALID, "upx_host_free: NULL plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipHostFree(ptr));
     return UPX_OK;
 }
 int upx_dev_memset(upx_plan* p, void* ptr, int value, size_t bytes) {
@@ -1031,14 +1091,13 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             const long long want = zoom_streams_wanted(p, s);
             long long f = s.blocks_override > 0 ? s.blocks_override : (frames + want - 1) / want;
             if (s.blocks_override <= 0) {
-                const char* fe = std::getenv("UPX_ZOOM_F");   // experiments: frames per stream
-                if (fe) f = std::atoll(fe);
+                if (p->knob_zoom_f > 0) f = p->knob_zoom_f;   // experiments: frames per stream
                 else if (f < 16) f = 16;
-                if (f > 64 && !fe) f = 64;
+                if (f > 64 && p->knob_zoom_f <= 0) f = 64;
             }
             if (f < s.k) f = s.k;
             f += f & 1;
-            const int cap = zoom_frames_cap(s.zoom_p);
+            const int cap = zoom_frames_cap(p, s.zoom_p);
             if (f > cap) f = cap;
             const long long n_streams = (frames + f - 1) / f;
             const long long tail = (long long)(s.k - 1) * s.hop;
@@ -1257,8 +1316,12 @@ int run_items(upx_plan* p, const std::vector<PipeItem>& items) {
         p->pipe_out_floats = out_floats;
     }
     const size_t plane = p->pipe_out_floats / 3;
-    const char* inject = std::getenv("UPX_TEST_FAIL_DOWNLOAD");   // test hook: fail the download of this item
+#if defined(UPX_TEST_HOOKS)   // never in the product library: a test build fails the download of this item
+    const char* inject = std::getenv("UPX_TEST_FAIL_DOWNLOAD");
     const int64_t inject_at = inject ? std::atoll(inject) : -1;
+#else
+    const int64_t inject_at = -1;
+#endif
 
     auto submit = [&](int64_t i, std::string& msg) -> int {
         const PipeItem& it = items[(size_t)i];
@@ -1310,11 +1373,8 @@ int run_items(upx_plan* p, const std::vector<PipeItem>& items) {
     return UPX_OK;
 }
 
-int64_t stream_chunk_default() {
-    // UPX_STREAM_CHUNK = owned samples per chunk of a long signal, 0 = never cut (one launch per track)
-    const char* env = std::getenv("UPX_STREAM_CHUNK");
-    return env ? std::atoll(env) : (1LL << 22);
-}
+// owned samples per chunk of a long signal (UPX_STREAM_CHUNK when the plan was created), 0 = never cut
+int64_t stream_chunk_default(const upx_plan* p) { return p->knob_stream_chunk; }
 }   // namespace
 
 int upx_process_chunked(upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r,
@@ -1337,7 +1397,7 @@ int upx_process(upx_plan* p, const float* stereo, int64_t n, float* out_c, float
     // long signals stream through the device in chunks (uploads, kernels and downloads overlap; no limit on the
     // length); short ones are a single work item of the same pipeline
     std::vector<PipeItem> items;
-    if (int rc = items_of_track(p, stereo, n, out_c, out_l, out_r, stream_chunk_default(), false, items)) return rc;
+    if (int rc = items_of_track(p, stereo, n, out_c, out_l, out_r, stream_chunk_default(p), false, items)) return rc;
     return run_items(p, items);
 }
 
@@ -1347,7 +1407,7 @@ int upx_process_tracks(upx_plan* p, int32_t n_tracks, const float* const* stereo
     if (n_tracks == 0) return UPX_OK;
     if (!stereo || !n || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process_tracks: NULL argument");
     std::vector<PipeItem> items;
-    const int64_t chunk = stream_chunk_default();
+    const int64_t chunk = stream_chunk_default(p);
     for (int32_t t = 0; t < n_tracks; ++t) {
         if (n[t] < 0) return fail(UPX_ERR_INVALID, "upx_process_tracks: track %d has a negative length", t);
         if (n[t] == 0) continue;
@@ -1509,13 +1569,129 @@ int upx_scale(upx_plan* p, float* d_x, int64_t n, float scale) {
     return UPX_OK;
 }
 
+namespace {
+int wav_bytes_of(int fmt) { return fmt == UPX_F32 ? 4 : fmt / 8; }
+bool wav_format_ok(int fmt) { return fmt == UPX_PCM16 || fmt == UPX_PCM24 || fmt == UPX_PCM32 || fmt == UPX_F32; }
+
+// device buffers of the WAV pipeline live in the plan and only grow: allocating and freeing ~0.8 GB per call costs
+// more than the kernels
+hipError_t wav_ensure(upx_plan* p, int slot, size_t bytes) {
+    if (bytes <= p->wav_cap[slot]) return hipSuccess;
+    if (p->d_wav[slot]) {
+        hipError_t e = hipFree(p->d_wav[slot]);
+        p->d_wav[slot] = nullptr;
+        p->wav_cap[slot] = 0;
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipMalloc(&p->d_wav[slot], bytes ? bytes : 4);
+    if (e == hipSuccess) p->wav_cap[slot] = bytes;
+    return e;
+}
+int ensure_copy_streams(upx_plan* p) {
+    if (p->s_h2d) return UPX_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&p->s_h2d, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p->s_d2h, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_h2d[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_comp[i], hipEventDisableTiming));
+    }
+    return UPX_OK;
+}
+}   // namespace
+
+int upx_wav_shard_begin(upx_plan* p, upx_comm* comm, const void* pcm_in, int in_format, int channels, int64_t t_in,
+                        int64_t own_len, int64_t t_out, int64_t spill, double* peaks) {
+    if (!p || !pcm_in || !peaks || t_in < 1 || own_len < 1 || own_len > t_in || t_out < own_len || spill < 0 ||
+        (channels != 1 && channels != 2))
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: bad argument");
+    if (!wav_format_ok(in_format)) return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: unknown sample format");
+    if (t_in >= (1LL << 29) || t_out >= (1LL << 29))
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: at most 2^29-1 frames per shard");
+    if (comm && comm->plan != p) return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: the communicator belongs to another plan");
+    const bool exchange = comm && comm->n_ranks > 1 && spill > 0;
+    if (exchange && comm->rank + 1 < comm->n_ranks && t_out < own_len + spill)
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: planes of a shard with a successor need own_len + spill samples");
+    HIP_TRY(hipSetDevice(p->device));
+    p->wav_open = false;
+    const int width = wav_bytes_of(in_format);
+    const size_t in_bytes = (size_t)t_in * channels * width;
+    HIP_TRY(wav_ensure(p, 0, in_bytes));
+    HIP_TRY(wav_ensure(p, 1, (size_t)t_in * 2 * sizeof(float)));
+    HIP_TRY(wav_ensure(p, 2, (size_t)t_out * 3 * sizeof(float)));
+    if (int rc = ensure_copy_streams(p)) return rc;
+    unsigned char* d_pcm = (unsigned char*)p->d_wav[0];
+    float* d_st = (float*)p->d_wav[1];
+    float* d_pl = (float*)p->d_wav[2];
+    for (auto& e : p->wav_ev)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+    hipStream_t st = p->stream;
+    HIP_TRY(hipEventRecord(p->wav_ev[0], st));
+    // the samples go up in pieces on the copy stream; each piece is decoded as soon as it has landed, so the decode
+    // (and, for the first pieces, nothing else) runs beside the rest of the upload
+    HIP_TRY(hipStreamWaitEvent(p->s_h2d, p->wav_ev[0], 0));   // the previous call's kernels have left the buffers
+    const int64_t piece = 1LL << 22;
+    int k = 0;
+    for (int64_t f0 = 0; f0 < t_in; f0 += piece, k ^= 1) {
+        const int64_t nf = t_in - f0 < piece ? t_in - f0 : piece;
+        const size_t off = (size_t)f0 * channels * width;
+        HIP_TRY(hipMemcpyAsync(d_pcm + off, (const unsigned char*)pcm_in + off, (size_t)nf * channels * width,
+                               hipMemcpyHostToDevice, p->s_h2d));
+        HIP_TRY(hipEventRecord(p->ev_h2d[k], p->s_h2d));
+        HIP_TRY(hipStreamWaitEvent(st, p->ev_h2d[k], 0));
+        hipLaunchKernelGGL(upx_decode_kernel, dim3(grid_for(nf)), dim3(256), 0, st, d_pcm + off, in_format, channels,
+                           (long long)nf, d_st + 2 * f0);
+    }
+    HIP_TRY(hipEventRecord(p->wav_ev[1], st));
+    if (int rc = upx_process_device(p, d_st, t_in, own_len, d_pl, d_pl + t_out, d_pl + 2 * t_out, t_out)) return rc;
+    if (exchange)
+        if (int rc = upx_comm_seam_exchange(comm, d_pl, d_pl + t_out, d_pl + 2 * t_out, own_len, spill)) return rc;
+    // peaks of the owned range: the input (both channels) and the three planes (main.py:53-55, :85-88)
+    float pk[4] = {0.f, 0.f, 0.f, 0.f};
+    if (int rc = upx_absmax(p, d_st, 2 * own_len, &pk[0])) return rc;
+    for (int i = 0; i < 3; ++i)
+        if (int rc = upx_absmax(p, d_pl + (size_t)i * t_out, own_len, &pk[1 + i])) return rc;
+    auto fmax_nan = [](float a, float b) { return (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b); };
+    peaks[0] = (double)pk[0];
+    peaks[1] = (double)fmax_nan(fmax_nan(pk[1], pk[2]), pk[3]);
+    p->wav_tin = t_in; p->wav_own = own_len; p->wav_tout = t_out;
+    p->wav_fmt = in_format; p->wav_ch = channels;
+    p->wav_open = true;
+    return UPX_OK;
+}
+
+int upx_wav_shard_finish(upx_plan* p, double scale, int mode, int out_format, void* out0, void* out1, void* out2) {
+    if (!p || !p->wav_open) return fail(UPX_ERR_INVALID, "upx_wav_shard_finish: no shard is open (call upx_wav_shard_begin)");
+    if (!wav_format_ok(out_format)) return fail(UPX_ERR_INVALID, "upx_wav_shard_finish: unknown sample format");
+    if (mode != UPX_EXPORT_STEREO_SUM && mode != UPX_EXPORT_SPLIT && mode != UPX_EXPORT_AB)
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_finish: unknown export mode");
+    const int n_out = mode == UPX_EXPORT_SPLIT ? 3 : 1;
+    void* outs[3] = {out0, out1, out2};
+    for (int i = 0; i < n_out; ++i)
+        if (!outs[i]) return fail(UPX_ERR_INVALID, "upx_wav_shard_finish: output buffer %d is NULL", i);
+    HIP_TRY(hipSetDevice(p->device));
+    const int64_t n = p->wav_own, t_out = p->wav_tout;
+    const size_t out_bytes = (size_t)n * 2 * wav_bytes_of(out_format);
+    for (int i = 0; i < n_out; ++i) HIP_TRY(wav_ensure(p, 3 + i, out_bytes));
+    unsigned char* d_o[3] = {(unsigned char*)p->d_wav[3], (unsigned char*)p->d_wav[4], (unsigned char*)p->d_wav[5]};
+    const float* d_pl = (const float*)p->d_wav[2];
+    hipStream_t st = p->stream;
+    hipLaunchKernelGGL(upx_export_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_pl, d_pl + t_out, d_pl + 2 * t_out,
+                       (const unsigned char*)p->d_wav[0], p->wav_fmt, p->wav_ch, (long long)n, scale, mode, out_format,
+                       d_o[0], d_o[1], d_o[2]);
+    HIP_TRY(hipEventRecord(p->wav_ev[2], st));
+    for (int i = 0; i < n_out; ++i) HIP_TRY(hipMemcpyAsync(outs[i], d_o[i], out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(p->wav_ev[3], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&p->pipe_ms[i], p->wav_ev[i], p->wav_ev[i + 1]);
+    p->wav_open = false;
+    return UPX_OK;
+}
+
 int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channels, int64_t n, int mode, int out_format,
                      void* out0, void* out1, void* out2, double* stats) {
-    auto bytes_of = [](int fmt) { return fmt == UPX_F32 ? 4 : fmt / 8; };
     if (!p || !pcm_in || n < 0 || (channels != 1 && channels != 2) || !stats)
         return fail(UPX_ERR_INVALID, "upx_wav_pipeline: bad argument");
-    if ((in_format != UPX_PCM16 && in_format != UPX_PCM24 && in_format != UPX_PCM32 && in_format != UPX_F32) ||
-        (out_format != UPX_PCM16 && out_format != UPX_PCM24 && out_format != UPX_PCM32 && out_format != UPX_F32))
+    if (!wav_format_ok(in_format) || !wav_format_ok(out_format))
         return fail(UPX_ERR_INVALID, "upx_wav_pipeline: unknown sample format");
     if (mode != UPX_EXPORT_STEREO_SUM && mode != UPX_EXPORT_SPLIT && mode != UPX_EXPORT_AB)
         return fail(UPX_ERR_INVALID, "upx_wav_pipeline: unknown export mode");
@@ -1526,71 +1702,14 @@ int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channel
     stats[0] = 1e-9; stats[1] = 1e-9; stats[2] = 1.0;
     if (n == 0) return UPX_OK;
     if (n >= (1LL << 29)) return fail(UPX_ERR_INVALID, "upx_wav_pipeline: at most 2^29-1 frames per call");
-    HIP_TRY(hipSetDevice(p->device));
-    const size_t in_bytes = (size_t)n * channels * bytes_of(in_format);
-    const size_t out_bytes = (size_t)n * 2 * bytes_of(out_format);
-    unsigned char *d_pcm = nullptr, *d_o[3] = {nullptr, nullptr, nullptr};
-    float *d_st = nullptr, *d_pl = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int rc = UPX_OK;
-    auto cleanup = [&]() {
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-    };
-#define PIPE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup(); return fail(UPX_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } } while (0)
-    // device buffers live in the plan and only grow: allocating and freeing ~0.8 GB per call costs more than the
-    // kernels.  (Pinning the caller's buffers with hipHostRegister for the two copies was dropped for the same
-    // reason: registering costs as much as it saves on a single pass over the data.)
-    auto ensure = [&](int slot, size_t bytes) -> hipError_t {
-        if (bytes <= p->wav_cap[slot]) return hipSuccess;
-        if (p->d_wav[slot]) {
-            hipError_t e = hipFree(p->d_wav[slot]);
-            p->d_wav[slot] = nullptr;
-            p->wav_cap[slot] = 0;
-            if (e != hipSuccess) return e;
-        }
-        hipError_t e = hipMalloc(&p->d_wav[slot], bytes);
-        if (e == hipSuccess) p->wav_cap[slot] = bytes;
-        return e;
-    };
-    PIPE_TRY(ensure(0, in_bytes));
-    PIPE_TRY(ensure(1, (size_t)n * 2 * sizeof(float)));
-    PIPE_TRY(ensure(2, (size_t)n * 3 * sizeof(float)));
-    for (int i = 0; i < n_out; ++i) PIPE_TRY(ensure(3 + i, out_bytes));
-    d_pcm = (unsigned char*)p->d_wav[0];
-    d_st = (float*)p->d_wav[1];
-    d_pl = (float*)p->d_wav[2];
-    for (int i = 0; i < n_out; ++i) d_o[i] = (unsigned char*)p->d_wav[3 + i];
-    for (auto& e : ev) PIPE_TRY(hipEventCreate(&e));
-    do {
-        hipStream_t st = p->stream;
-        if (hipEventRecord(ev[0], st) != hipSuccess) { rc = fail(UPX_ERR_HIP, "event"); break; }
-        if (hipMemcpyAsync(d_pcm, pcm_in, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = fail(UPX_ERR_HIP, "H2D copy failed"); break; }
-        (void)hipEventRecord(ev[1], st);
-        hipLaunchKernelGGL(upx_decode_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_pcm, in_format, channels, (long long)n, d_st);
-        rc = upx_process_device(p, d_st, n, n, d_pl, d_pl + n, d_pl + 2 * n, n);
-        if (rc) break;
-        float peak_in = 0.f, peak_out = 0.f;
-        rc = upx_absmax(p, d_st, 2 * n, &peak_in);
-        if (!rc) rc = upx_absmax(p, d_pl, 3 * n, &peak_out);
-        if (rc) break;
-        const double pin = peak_in <= 0.f ? 1e-9 : (double)peak_in;                 // main.py:53-55
-        const double overall = (double)peak_out > 1e-9 ? (double)peak_out : 1e-9;   // main.py:88
-        const double scale = pin / overall;                                         // main.py:90
-        stats[0] = pin; stats[1] = overall; stats[2] = scale;
-        hipLaunchKernelGGL(upx_export_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_pl, d_pl + n, d_pl + 2 * n, d_pcm,
-                           in_format, channels, (long long)n, scale, mode, out_format, d_o[0], d_o[1], d_o[2]);
-        (void)hipEventRecord(ev[2], st);
-        bool bad = false;
-        for (int i = 0; i < n_out; ++i)
-            bad |= hipMemcpyAsync(outs[i], d_o[i], out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess;
-        (void)hipEventRecord(ev[3], st);
-        hipError_t se = hipStreamSynchronize(st);
-        if (bad || se != hipSuccess) { rc = fail(UPX_ERR_HIP, "kernel or D2H copy failed: %s", hipGetErrorString(se)); break; }
-        for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&p->pipe_ms[i], ev[i], ev[i + 1]);
-    } while (0);
-    cleanup();
-#undef PIPE_TRY
-    return rc;
+    // one shard that is the whole file: the two halves of the sharded pipeline with the scale of this file alone
+    double peaks[2];
+    if (int rc = upx_wav_shard_begin(p, nullptr, pcm_in, in_format, channels, n, n, n, 0, peaks)) return rc;
+    const double pin = peaks[0] <= 0.0 ? 1e-9 : peaks[0];                  // main.py:53-55 (a NaN peak stays NaN)
+    const double overall = peaks[1] > 1e-9 || peaks[1] != peaks[1] ? peaks[1] : 1e-9;   // main.py:88: max(.., 1e-9)
+    const double scale = pin / overall;                                   // main.py:90
+    stats[0] = pin; stats[1] = overall; stats[2] = scale;
+    return upx_wav_shard_finish(p, scale, mode, out_format, out0, out1, out2);
 }
 
 int upx_wav_pipeline_times_ms(upx_plan* p, float* ms3) {

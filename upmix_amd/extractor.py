@@ -18,18 +18,23 @@ from __future__ import annotations
 
 import ctypes as C
 import contextlib
+import os
 import threading
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import _lib
+from . import _lib, hostmem
 from .plan import (band_limit_gain, compute_block_size_for_low_freq, design_wola_synthesis_window,
                    hp_freq_to_crossover_width)
 
 
 def _f32p(a: np.ndarray):
     return a.ctypes.data_as(_lib.f32p)
+
+
+_LIVE_PLANS = [0]
+_LIVE_PLANS_LOCK = threading.Lock()
 
 
 class DevicePlan:
@@ -57,6 +62,8 @@ class DevicePlan:
         # (center_extraction.py:499-501), so calls on ONE plan are serialised here; distinct plans run concurrently
         self.lock = threading.RLock()
         self._users = 0   # checked out of the plan cache (see _checked_out_plan)
+        with _LIVE_PLANS_LOCK:
+            _LIVE_PLANS[0] += 1
 
     # -- whole signal, host buffers -----------------------------------------
     def process(self, stereo: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -65,7 +72,7 @@ class DevicePlan:
         if x.ndim != 2 or x.shape[1] != 2:
             raise ValueError("stereo must have shape [T, 2]")
         total = x.shape[0]
-        out = [np.empty(total, dtype=np.float32) for _ in range(3)]
+        out = [self.host_empty(total, np.float32) for _ in range(3)]   # pooled page-locked memory (hostmem.py)
         if total == 0:
             return tuple(out)
         # any length: the library streams long signals through the device in chunks (upx_process_chunked)
@@ -84,7 +91,7 @@ class DevicePlan:
             if x.ndim != 2 or x.shape[1] != 2:
                 raise ValueError("every track must have shape [T, 2]")
         n = len(xs)
-        outs = [[np.empty(x.shape[0], dtype=np.float32) for _ in range(3)] for x in xs]
+        outs = [[self.host_empty(x.shape[0], np.float32) for _ in range(3)] for x in xs]
         if n == 0:
             return []
         lens = (C.c_int64 * n)(*[x.shape[0] for x in xs])
@@ -100,11 +107,16 @@ class DevicePlan:
         if x.ndim != 2 or x.shape[1] != 2:
             raise ValueError("stereo must have shape [T, 2]")
         total = x.shape[0]
-        out = [np.empty(total, dtype=np.float32) for _ in range(3)]
+        out = [self.host_empty(total, np.float32) for _ in range(3)]
         if total:
             with self.lock:
                 _lib.check(self._lib.upx_process_chunked(self.handle, _f32p(x), total, *(_f32p(o) for o in out), int(chunk)))
         return tuple(out)
+
+    def host_empty(self, shape, dtype=np.uint8) -> np.ndarray:
+        """np.empty(shape, dtype) in pooled page-locked host memory (falls back to pageable memory beyond the pool's
+        limit): the arrays this plan's host-buffer calls return, and the staging buffers of the file entries."""
+        return hostmem.empty(shape, dtype, self.handle)
 
     # -- device-resident helpers --------------------------------------------
     def alloc(self, nbytes: int) -> int:
@@ -203,19 +215,48 @@ class DevicePlan:
         ({"Sum"|"AB"|"Ls","C","Rs": uint8 payload}, {"peak_in", "overall_peak", "scale_factor"}).
         main.py:43-160; `mode` in ("stereo_sum", "split", "AB").
         """
-        modes = {"stereo_sum": (_lib.EXPORT_STEREO_SUM, ("Sum",)), "split": (_lib.EXPORT_SPLIT, ("Ls", "C", "Rs")),
-                 "AB": (_lib.EXPORT_AB, ("AB",))}
-        if mode not in modes:
+        if mode not in self._MODES:
             raise ValueError(f"unknown export mode {mode!r}")
-        code, names = modes[mode]
+        code, names = self._MODES[mode]
         width = 4 if out_format == _lib.F32 else out_format // 8
         src = np.ascontiguousarray(pcm).view(np.uint8)
-        outs = [np.empty(n_frames * 2 * width, dtype=np.uint8) for _ in names]
+        outs = [self.host_empty(n_frames * 2 * width) for _ in names]
         ptrs = [o.ctypes.data_as(C.c_void_p) for o in outs] + [None] * (3 - len(outs))
         stats = (C.c_double * 3)()
         _lib.check(self._lib.upx_wav_pipeline(self.handle, src.ctypes.data_as(C.c_void_p), int(in_format), int(channels),
                                               int(n_frames), code, int(out_format), ptrs[0], ptrs[1], ptrs[2], stats))
         return dict(zip(names, outs)), {"peak_in": stats[0], "overall_peak": stats[1], "scale_factor": stats[2]}
+
+    _MODES = {"stereo_sum": (_lib.EXPORT_STEREO_SUM, ("Sum",)), "split": (_lib.EXPORT_SPLIT, ("Ls", "C", "Rs")),
+              "AB": (_lib.EXPORT_AB, ("AB",))}
+
+    def wav_shard_begin(self, pcm: np.ndarray, in_format: int, channels: int, t_in: int, own_len: int, t_out: int,
+                        spill: int = 0, seam=None):
+        """
+        First half of the WAV pipeline for one time shard (upx_wav_shard_begin): raw samples up, decode, all bands, the
+        RCCL seam (`seam` = sharding.RcclSeam or None), peaks of the owned range.  -> (peak_in, peak_out) as the device
+        found them (0 for silence, NaN if a NaN was seen); the caller reduces them over the ranks.
+        """
+        src = np.ascontiguousarray(pcm).view(np.uint8)
+        peaks = (C.c_double * 2)()
+        with self.lock:
+            _lib.check(self._lib.upx_wav_shard_begin(self.handle, seam.handle if seam is not None else None,
+                                                     src.ctypes.data_as(C.c_void_p), int(in_format), int(channels),
+                                                     int(t_in), int(own_len), int(t_out), int(spill), peaks))
+        return float(peaks[0]), float(peaks[1])
+
+    def wav_shard_finish(self, scale: float, mode: str, out_format: int, n_frames: int):
+        """Second half: scale, export layout, quantisation on the device; -> {name: uint8 payload of n_frames frames}."""
+        if mode not in self._MODES:
+            raise ValueError(f"unknown export mode {mode!r}")
+        code, names = self._MODES[mode]
+        width = 4 if out_format == _lib.F32 else out_format // 8
+        outs = [self.host_empty(n_frames * 2 * width) for _ in names]
+        ptrs = [o.ctypes.data_as(C.c_void_p) for o in outs] + [None] * (3 - len(outs))
+        with self.lock:
+            _lib.check(self._lib.upx_wav_shard_finish(self.handle, float(scale), code, int(out_format), ptrs[0], ptrs[1],
+                                                      ptrs[2]))
+        return dict(zip(names, outs))
 
     def wav_pipeline_times_ms(self):
         ms = np.zeros(3, dtype=np.float32)
@@ -229,6 +270,11 @@ class DevicePlan:
     def close(self) -> None:
         if getattr(self, "handle", None) is not None and self.handle:
             with self.lock:
+                with _LIVE_PLANS_LOCK:
+                    _LIVE_PLANS[0] -= 1
+                    last = _LIVE_PLANS[0] == 0
+                if last:
+                    hostmem.POOL.trim(self.handle)   # idle page-locked blocks go back while a device context exists
                 self._lib.upx_plan_destroy(self.handle)
                 self.handle = None
 
@@ -359,7 +405,9 @@ def _checked_out_plan(band_extractors: Sequence[MultiBandExtractorAccu], device:
     look-up, creation and eviction happen under one lock, and a plan that some thread is using is never evicted
     (the cache may exceed its size for that long).
     """
-    key = (tuple(_band_signature(b) for b in band_extractors), device)
+    # (the library reads its UPX_* tuning knobs when a plan is created: a plan made under other settings is another plan)
+    knobs = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("UPX_")))
+    key = (tuple(_band_signature(b) for b in band_extractors), device, knobs)
     with _PLAN_CACHE_LOCK:
         plan = _PLAN_CACHE.pop(key, None)
         if plan is None:

@@ -1,0 +1,117 @@
+"""
+Page-locked host buffers for the arrays that cross PCIe (upx_host_alloc in the C ABI).
+
+A call into fresh pageable NumPy arrays spends most of its time outside the link: the kernel faults in and zeroes
+every new page, the runtime stages the copy through its own pinned bounce buffer, and the arrays' release unmaps the
+pages again (measured on the MI355X box, 10 min of 48 kHz stereo: 8 ms into arrays that were touched before, 39 ms
+into fresh ones).  The pool hands out NumPy arrays that live in page-locked blocks instead: the copy
+engine writes straight into them at link speed, and a block goes back to the pool when the last array (or view) on
+it is garbage collected, so the next call reuses it - no allocation, no faults.
+
+The reference returns fresh NumPy arrays (center_extraction.py:503-513) that the caller owns and scales in place
+(main.py:95-97); arrays from the pool behave the same (owned by the caller, writable, any lifetime).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Dict, List
+
+import numpy as np
+
+from . import _lib
+
+_GRANULE = 1 << 21   # block sizes are multiples of 2 MiB
+
+
+class _Lease:
+    """Owner object of one block: NumPy arrays made from it keep it alive; its death returns the block."""
+
+    def __init__(self, pool: "PinnedPool", ptr: int, cap: int, nbytes: int):
+        self._pool, self._ptr, self._cap = pool, ptr, cap
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    def __del__(self):
+        pool, self._pool = self._pool, None
+        if pool is not None:
+            pool._give_back(self._ptr, self._cap)
+
+
+class PinnedPool:
+    """Blocks of page-locked memory of one device plan's process, recycled by capacity."""
+
+    def __init__(self, limit_bytes: int):
+        self.limit = int(limit_bytes)
+        self._free: Dict[int, List[int]] = {}
+        self._held = 0            # bytes pinned by this pool (free + leased)
+        self._lock = threading.Lock()
+        self._plan_handle = None  # any live upx_plan of the process (allocation needs a device context)
+        self.closed = False
+
+    def take(self, nbytes: int, plan_handle) -> np.ndarray:
+        """uint8[nbytes] in page-locked memory; plain pageable memory if the pool is at its limit or pinning fails."""
+        nbytes = int(nbytes)
+        if nbytes <= 0 or self.closed or self.limit <= 0:
+            return np.empty(max(nbytes, 0), dtype=np.uint8)
+        cap = -(-nbytes // _GRANULE) * _GRANULE
+        lib = _lib.load()
+        with self._lock:
+            stack = self._free.get(cap)
+            ptr = stack.pop() if stack else None
+            if ptr is None:
+                # make room by releasing idle blocks of other sizes before giving up
+                while self._held + cap > self.limit and any(self._free.values()):
+                    k = max((k for k, v in self._free.items() if v), default=None)
+                    if k is None:
+                        break
+                    lib.upx_host_free(plan_handle, C.c_void_p(self._free[k].pop()))
+                    self._held -= k
+                if self._held + cap > self.limit:
+                    return np.empty(nbytes, dtype=np.uint8)
+                p = C.c_void_p()
+                if lib.upx_host_alloc(plan_handle, C.byref(p), cap) != _lib.UPX_OK or not p.value:
+                    return np.empty(nbytes, dtype=np.uint8)
+                ptr = p.value
+                self._held += cap
+            self._plan_handle = plan_handle
+        return np.asarray(_Lease(self, ptr, cap, nbytes))
+
+    def _give_back(self, ptr: int, cap: int) -> None:
+        with self._lock:
+            if not self.closed:
+                self._free.setdefault(cap, []).append(ptr)
+                return
+        # the pool is closed (interpreter exit): the block stays with the process; the runtime frees it at unload
+
+    def trim(self, plan_handle) -> None:
+        """Release every idle block (called when the last plan closes, while a device context still exists)."""
+        lib = _lib.load()
+        with self._lock:
+            for cap, stack in self._free.items():
+                while stack:
+                    lib.upx_host_free(plan_handle, C.c_void_p(stack.pop()))
+                    self._held -= cap
+
+    def close(self) -> None:
+        with self._lock:
+            self.closed = True
+
+
+def _limit_from_env() -> int:
+    """UPX_PINNED_POOL_MB (read once): cap of the pool, default 8 GiB, 0 disables it."""
+    try:
+        return int(os.environ.get("UPX_PINNED_POOL_MB", "8192")) << 20
+    except ValueError:
+        return 8192 << 20
+
+
+POOL = PinnedPool(_limit_from_env())
+
+
+def empty(nbytes_or_shape, dtype, plan_handle) -> np.ndarray:
+    """np.empty(shape, dtype) in pooled page-locked memory."""
+    shape = (nbytes_or_shape,) if np.isscalar(nbytes_or_shape) else tuple(nbytes_or_shape)
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    return POOL.take(n, plan_handle).view(dt).reshape(shape)

@@ -7,98 +7,166 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, e.g.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
         -m upmix_amd.multi_gpu eyes.wav --export-mode stereo_sum
 
-Every rank reads ONLY its own time shard (+ the right halo) from the input file and writes ONLY its own slice of
-every output file, at that slice's byte offset (rank 0 writes the headers first); nothing but two scalars per rank
-(input peak, output peak: the one global scale of main.py:85-97) and the RCCL unique id crosses the process group
-(torch.distributed gloo), and nothing but the overlap-add seam crosses RCCL.  The export arithmetic is main.py's
-(:110-157), on each rank's slice.
+Every rank reads ONLY the bytes of its own time shard (+ the right halo) from the input file, straight into
+page-locked memory, and writes ONLY its own slice of every output file at that slice's byte offset (rank 0 writes
+the headers first).  Between the two, everything runs on the rank's GPU (upx_wav_shard_begin / _finish): the raw
+samples go up, are decoded, upmixed, the overlap-add seam crosses RCCL, a device max-reduce finds the shard's peaks;
+the two scalars cross the process group (upmix_amd.rendezvous: standard-library sockets - no torch in this
+process); then scale, export layout (main.py:110-157) and quantisation run on the device and only final 2-channel
+sample data comes down.  `--host-export`, files with more than two channels and sample formats the device codec does
+not read take the NumPy flow of round 2 (decode, scale and export on the host, float64 like main.py).
 """
 from __future__ import annotations
 
 import argparse
+import math
 import os
 import sys
+import time
 from typing import Callable, Optional
 
 import numpy as np
 
 from . import export, sharding, wav
 from .plan import WINDOW_FUNCS
+from .rendezvous import Rendezvous
+
+_SUBTYPE_KIND = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32, "FLOAT": 1032}
+
+
+class _Solo:
+    """The process group of a single rank."""
+    rank, world = 0, 1
+
+    def allreduce_max(self, values):
+        return [float(v) for v in values]
+
+    def broadcast_bytes(self, payload, src=0):
+        return payload
+
+    def barrier(self):
+        pass
+
+    def all_ok(self, ok=True, message=""):
+        if not ok:
+            raise RuntimeError(message)
+
+
+def _global_scale(peak_in: float, peak_out: float):
+    """main.py:53-55 and :85-90 on the maxima over all ranks -> (peak_in, overall_peak, scale_factor float64)."""
+    if peak_in <= 0.0:                       # (a NaN peak stays NaN, as in main.py)
+        peak_in = 1e-9
+    overall = peak_out if math.isnan(peak_out) else max(peak_out, 1e-9)
+    return peak_in, overall, np.float64(peak_in / overall)
 
 
 def run_rank(in_path: str, out_dir: str, export_mode: str, bands, overlap: float, subtype: str, rank: int, world: int,
-             dist, engine: Optional[Callable] = None, device: int = 0, log=print):
+             group=None, engine: Optional[Callable] = None, device: int = 0, log=print, host_export: bool = False,
+             times: Optional[dict] = None):
     """
     One rank's part of the job; returns {key: path} of the files (written by all ranks together).
-    `engine(local_stereo, shard, geo) -> (center, left, right)` for the samples the shard owns, seam included;
-    default: this rank's GPU (DevicePlan + RCCL seam).  The CPU tests plug the oracle + a gloo seam in.
-    `dist` = an initialised torch.distributed module (any backend that can all-reduce CPU tensors), or None if world == 1.
+    `group`: the process group (rendezvous.Rendezvous or anything with allreduce_max / broadcast_bytes / barrier /
+    all_ok); None for a single rank.  `engine(local_stereo, shard, geo) -> (center, left, right)` replaces the GPU (the
+    CPU tests plug the oracle + their own seam in) and implies the host flow.  `times`: filled with seconds per phase.
     """
+    group = group if group is not None else _Solo()
+    t_mark = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        if times is not None:
+            times[name] = times.get(name, 0.0) + now - t_mark[0]
+        t_mark[0] = now
+
+    # ---- everything that can be refused is checked on EVERY rank before any GPU work or barrier ----------------
     meta = wav.info(in_path)
     total, sr, channels = meta["n_frames"], meta["rate"], meta["channels"]
+    wav.subtype_layout(subtype)                                            # ValueError for an unknown subtype
     geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
     shard = geo.plan(total, world)[rank]
-    local = wav.read_range(in_path, shard.start, shard.t_in, meta)        # own range + right halo, nothing else
-    if local.ndim == 1:
-        local = np.column_stack([local, local])                            # main.py:47-48
-    own = local[:shard.own_len]
+    names = export.export_file_names(os.path.splitext(os.path.basename(in_path))[0], export_mode, bands, overlap)
+    if not names and rank == 0:
+        log(f"Unknown export_mode '{export_mode}' -- no files written.")     # main.py:159-160
+    try:
+        kind = wav.device_kind(meta, in_path)
+    except ValueError:
+        kind = None
+    on_device = engine is None and not host_export and kind is not None and channels in (1, 2) and bool(names)
 
     plan = seam = None
-    if engine is None:
-        from .extractor import DevicePlan
-        plan = DevicePlan(bands, device)
-        if world > 1:
-            seam = sharding.RcclSeam(plan, rank, world, broadcast=lambda b: sharding.broadcast_bytes_gloo(dist, b))
-        c, l, r = sharding.process_local_shard(plan, local, shard, geo, world, seam)
-    else:
-        c, l, r = engine(local, shard, geo)
+    try:
+        if engine is None:
+            from .extractor import DevicePlan
+            plan = DevicePlan(bands, device)
+            if world > 1:
+                seam = sharding.RcclSeam(plan, rank, world, broadcast=group.broadcast_bytes)
+        spill = geo.spill if world > 1 else 0
+        if on_device:
+            # raw bytes of the shard -> page-locked memory -> GPU; nothing is decoded on the host
+            block = meta["bits"] // 8 * channels
+            raw = wav.read_raw_range(in_path, shard.start, shard.t_in, meta, out=plan.host_empty(shard.t_in * block))
+            lap("read_s")
+            t_out = shard.own_len + (0 if shard.last else spill)
+            peaks = plan.wav_shard_begin(raw, kind, channels, shard.t_in, shard.own_len, t_out, spill, seam)
+            lap("device_begin_s")
+            peak_in, overall_peak, scale_factor = _global_scale(*group.allreduce_max(peaks))
+            payloads = plan.wav_shard_finish(float(scale_factor), export_mode, _SUBTYPE_KIND[subtype], shard.own_len)
+            lap("device_finish_s")
+        else:
+            local = wav.read_range(in_path, shard.start, shard.t_in, meta)     # own range + right halo, nothing else
+            if local.ndim == 1:
+                local = np.column_stack([local, local])                        # main.py:47-48
+            own = local[:shard.own_len]
+            stereo = np.ascontiguousarray(local[:, :2])                        # main.py:49-50: wave[:,0], wave[:,1]
+            lap("read_s")
+            if engine is None:
+                c, l, r = sharding.process_local_shard(plan, stereo, shard, geo, world, seam)
+            else:
+                c, l, r = engine(stereo, shard, geo)
+            lap("device_begin_s")
+            # one global scale (main.py:53-55, :85-97): maxima over the ranks; the input peak is over ALL channels
+            mine = [float(np.max(np.abs(own), initial=0.0)),
+                    max(float(np.max(np.abs(l), initial=0.0)), float(np.max(np.abs(c), initial=0.0)),
+                        float(np.max(np.abs(r), initial=0.0)), 0.0)]
+            peak_in, overall_peak, scale_factor = _global_scale(*group.allreduce_max(mine))
+            # main.py:90-97: scale_factor is a float64 NumPy scalar there, so `final_x *= scale_factor` multiplies in
+            # float64 and rounds once to float32
+            for p in (c, l, r):
+                p *= scale_factor
+            arrays = export.export_arrays(export_mode, c, l, r, own[:, 0], own[:, 1])
+            payloads = {key: np.frombuffer(wav.encode(arr, subtype)[2], dtype=np.uint8) for key, arr in arrays.items()}
+            lap("device_finish_s")
 
-    # one global scale (main.py:53-55, :85-97): max over the ranks of the input peak and of the output peak
-    peaks = np.array([float(np.max(np.abs(own), initial=0.0)),
-                      max(float(np.max(np.abs(c), initial=0.0)), float(np.max(np.abs(l), initial=0.0)),
-                          float(np.max(np.abs(r), initial=0.0)))], dtype=np.float64)
-    if world > 1:
-        import torch   # only with a process group: a single rank never loads torch next to libupmix_hip.so
-        t = torch.from_numpy(peaks)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    peak_in = float(peaks[0]) if float(peaks[0]) > 0.0 else 1e-9
-    overall_peak = max(float(peaks[1]), 1e-9)
-    # main.py:90-97: peak_in and the plane maxima are NumPy scalars there, so scale_factor is a float64 NumPy scalar and
-    # `final_x *= scale_factor` multiplies in float64 and rounds once to float32 (a Python float would multiply in float32)
-    scale_factor = np.float64(peak_in / overall_peak)
-    for p in (c, l, r):
-        p *= scale_factor
-    arrays = export.export_arrays(export_mode, c, l, r, own[:, 0], own[:, 1])
-    names = export.export_file_names(os.path.splitext(os.path.basename(in_path))[0], export_mode, bands, overlap)
-    written = {}
-    if rank == 0:
-        log(f"Original peak = {peak_in:.4f}, L/C/R peak = {overall_peak:.4f}")
-        log(f"Applying scale_factor = {scale_factor:.4f}")
-        os.makedirs(out_dir, exist_ok=True)
-        if not arrays:
-            log(f"Unknown export_mode '{export_mode}' -- no files written.")     # main.py:159-160
-        for key in arrays:
-            wav.create(os.path.join(out_dir, names[key]), total, sr, subtype, 2)   # header + full size
-    if world > 1:
-        dist.barrier()                                                      # headers exist before anyone writes a slice
-    for key, arr in arrays.items():
-        path = os.path.join(out_dir, names[key])
-        code, bits, payload = wav.encode(arr, subtype)
-        block = 2 * bits // 8
-        data_offset = wav.info(path)["data_offset"]
-        wav.write_at(path, data_offset + shard.start * block, payload)
-        written[key] = path
-    if world > 1:
-        dist.barrier()
-    if rank == 0:
-        for key, path in written.items():
-            log(f"Wrote => {path}")
-        log("Done.")
-    if seam is not None:
-        seam.close()
-    if plan is not None:
-        plan.close()
-    return written
+        # ---- rank 0 creates the files; its outcome reaches every rank before anyone waits or writes -------------
+        err = ""
+        if rank == 0:
+            try:
+                log(f"Original peak = {peak_in:.4f}, L/C/R peak = {overall_peak:.4f}")
+                log(f"Applying scale_factor = {scale_factor:.4f}")
+                os.makedirs(out_dir, exist_ok=True)
+                for key in payloads:
+                    wav.create(os.path.join(out_dir, names[key]), total, sr, subtype, 2)   # header + full (sparse) size
+            except Exception as exc:   # noqa: BLE001 - reported to every rank, raised by all_ok
+                err = f"{type(exc).__name__}: {exc}"
+        group.all_ok(not err, err)
+        written = {}
+        _, bits = wav.subtype_layout(subtype)
+        for key, payload in payloads.items():
+            path = os.path.join(out_dir, names[key])
+            wav.write_at(path, wav.info(path)["data_offset"] + shard.start * (2 * bits // 8), payload)
+            written[key] = path
+        lap("write_s")
+        group.barrier()
+        if rank == 0:
+            for key, path in written.items():
+                log(f"Wrote => {path}")
+            log("Done.")
+        return written
+    finally:
+        if seam is not None:
+            seam.close()
+        if plan is not None:
+            plan.close()
 
 
 def main(argv=None) -> int:
@@ -113,37 +181,28 @@ def main(argv=None) -> int:
     ap.add_argument("--xover-mode", default="raised_cosine")
     ap.add_argument("--max-stft", type=int, default=8192)
     ap.add_argument("--subtype", default="PCM_16", choices=["PCM_16", "PCM_24", "PCM_32", "FLOAT"])
+    ap.add_argument("--host-export", action="store_true", help="decode / scale / export with NumPy on the host")
+    ap.add_argument("--timing", action="store_true", help="print this rank's seconds per phase")
     a = ap.parse_args(argv)
 
     from .extractor import chain_bands
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
     in_path = os.path.join(a.in_dir, a.in_filename)
     if not os.path.isfile(in_path):
         raise FileNotFoundError(f"File not found: {in_path}")              # main.py:40-41
-    sr = wav.info(in_path)["rate"]
-    bands = chain_bands([float(v) for v in a.band_edges.split(",")], a.overlap, WINDOW_FUNCS[a.window], sr,
-                        a.xover_mode, max_block_size=a.max_stft, device=local_rank, verbose=rank == 0)
-    run_rank(in_path, a.out_dir, a.export_mode, bands, a.overlap, a.subtype, rank, world, dist, device=local_rank,
-             log=print if rank == 0 else (lambda *_: None))
-    if dist is not None:
-        dist.destroy_process_group()
+    with Rendezvous.from_env() as group:
+        rank, world = group.rank, group.world
+        sr = wav.info(in_path)["rate"]
+        bands = chain_bands([float(v) for v in a.band_edges.split(",")], a.overlap, WINDOW_FUNCS[a.window], sr,
+                            a.xover_mode, max_block_size=a.max_stft, device=local_rank, verbose=rank == 0)
+        times = {}
+        run_rank(in_path, a.out_dir, a.export_mode, bands, a.overlap, a.subtype, rank, world,
+                 group if world > 1 else None, device=local_rank, log=print if rank == 0 else (lambda *_: None),
+                 host_export=a.host_export, times=times)
+        if a.timing:
+            print(f"[rank {rank}] " + ", ".join(f"{k} {v:.3f}" for k, v in times.items()), flush=True)
     return 0
 
 
 if __name__ == "__main__":
-    rc = main()
-    sys.stdout.flush()
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        # torch (its own bundled HIP runtime) and libupmix_hip.so (the system one) share this process: skip the
-        # interpreter's teardown, where the two runtimes' exit handlers can collide
-        os._exit(rc)
-    sys.exit(rc)
+    sys.exit(main())

@@ -181,7 +181,9 @@ def process_rank(plan, stereo: np.ndarray, rank: int, world: int, seam: Optional
 
 
 class RcclSeam:
-    """One RCCL communicator per process/GPU for the seam all-reduce (upx_comm_* in the C ABI)."""
+    """One RCCL communicator per process/GPU for the seam all-reduce (upx_comm_* in the C ABI).
+    `broadcast(payload_or_None) -> bytes` hands rank 0's 128-byte RCCL id to every rank (rendezvous.Rendezvous
+    .broadcast_bytes in the product entries)."""
 
     def __init__(self, plan, rank: int, world: int, broadcast: Callable[[Optional[bytes]], bytes]):
         self._lib = _lib.load()
@@ -209,13 +211,3 @@ class RcclSeam:
         if self.handle:
             self._lib.upx_comm_destroy(self.handle)
             self.handle = None
-
-
-def broadcast_bytes_gloo(dist, payload: Optional[bytes], nbytes: int = _lib.UNIQUE_ID_BYTES) -> bytes:
-    """Share rank 0's bytes with every rank over an existing torch.distributed (gloo) group."""
-    import torch
-    t = torch.zeros(nbytes, dtype=torch.uint8)
-    if payload is not None:
-        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
-    dist.broadcast(t, src=0)
-    return bytes(t.numpy().tobytes())
