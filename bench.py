@@ -41,7 +41,11 @@ HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32 vector peak (SURVEY.md 8(d) secondary ceiling)
 ALGO_BYTES_IN, ALGO_BYTES_OUT = 8, 12   # per band 8 B stereo in + 12 B Ls/C/Rs out = 20 B per sample
 KERNEL_SOURCES = ["upmix_amd/csrc/upx_core.h", "upmix_amd/csrc/upx_zoom.h", "upmix_amd/csrc/upx_big.h",
-                  "upmix_amd/csrc/upx_lib.hip"]
+                  "upmix_amd/csrc/upx_kernels.h", "upmix_amd/csrc/upx_lib.hip", "upmix_amd/csrc/upx_reg_big.hip",
+                  "upmix_amd/csrc/upx_reg_fused.hip", "upmix_amd/csrc/upx_reg_fused_single.hip",
+                  "upmix_amd/csrc/upx_reg_fused_p8.hip", "upmix_amd/csrc/upx_reg_fused_plain.hip",
+                  "upmix_amd/csrc/upx_reg_zoom256.hip", "upmix_amd/csrc/upx_reg_zoom512.hip",
+                  "upmix_amd/csrc/upx_reg_zoom1024.hip"]
 
 WORKLOADS = {
     #          sr     seconds  max_stft  BASELINE config
@@ -192,6 +196,41 @@ def e2e_rates(ux, plan, bands, sr, nominal):
     out["note"] = ("pageable input buffers; best of 3; PCIe-inclusive, reported beside `value` (which is HBM-resident), "
                    "SURVEY.md 8(d)")
     return out
+
+
+def e2e_multi_gpu_file(bands, sr, nominal, device):
+    """
+    The product's one-WAV-over-N-GPUs entry (upmix_amd.multi_gpu.run_rank) on this GPU's share, file to file: a PCM_24
+    WAV of the workload's signal is written to a scratch directory, then one rank reads its bytes into page-locked
+    memory, runs the sharded device pipeline (upx_wav_shard_begin / _finish) and writes its slice of the PCM_24 output.
+    Second of two runs (page cache and the pinned pool warm); seconds per phase as run_rank measures them.
+    """
+    import shutil
+    import tempfile
+    from upmix_amd import multi_gpu, wav
+    tmp = tempfile.mkdtemp(prefix="upx_bench_", dir=os.environ.get("UPX_BENCH_TMP", None))
+    try:
+        path = os.path.join(tmp, "share.wav")
+        off = wav.create(path, nominal, sr, "PCM_24", 2)
+        step = 1 << 22
+        for a in range(0, nominal, step):                       # in pieces: no full-length float64 temporaries
+            n = min(step, nominal - a)
+            wav.write_at(path, off + a * 6, wav.encode(synth(n, (2, a)).astype(np.float64), "PCM_24")[2])
+        best = None
+        for _ in range(2):
+            times = {}
+            t0 = time.perf_counter()
+            multi_gpu.run_rank(path, os.path.join(tmp, "out"), "stereo_sum", bands, 0.75, "PCM_24", 0, 1, None,
+                               device=device, log=lambda *_: None, times=times)
+            times["total_s"] = time.perf_counter() - t0
+            best = times
+        return {"multi_gpu_run_rank_pcm24_stereo_sum": {k: round(v * 1e3, 1) for k, v in best.items()},
+                "unit": "ms", "Msamples_per_s": round(nominal / best["total_s"] / 1e6, 1),
+                "note": "file -> file on one rank: read_s = the shard's bytes from the (cached) file into page-locked memory; "
+                        "device_begin_s = upload + decode + all bands + peaks; device_finish_s = scale + export + "
+                        "quantise + download; write_s = header + this rank's slice; plan creation included in total_s"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -467,6 +506,8 @@ def main():
                     del tracks
                 else:
                     out["e2e"] = e2e_rates(ux, plan, bands, sr, nominal)
+                    if args.workload == "c4share":
+                        out["e2e"].update(e2e_multi_gpu_file(bands, sr, nominal, local_rank))
             except Exception as exc:   # a side measurement must not take the bench line down
                 out["e2e"] = {"error": repr(exc)}
         else:
