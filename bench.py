@@ -129,10 +129,18 @@ def executed_flops_per_sample(kernel_name, n, k, n_bands_in_launch, phase):
     return 12.5 * k * np.log2(n) + 80.0 * n_bands_in_launch
 
 
-def load_pmc_traffic(kernel_tag):
+def canonical_kernel_name(name):
+    """One spelling for a kernel whether the library's table or rocprofv3 names it: no blanks ("> >"), no default
+    template arguments (rocprofv3 prints upx::Live<0, 1048576> for the general flavour), no namespace of the symbol."""
+    name = name.replace(" ", "").replace(",upx::Live<0,1048576>", "")
+    return re.sub(r"^(void)?(\(anonymousnamespace\)::|upxk::)?", "", name)
+
+
+def load_pmc_traffic(kernel_tag, workload="c3"):
     """
-    HBM bytes per launch of `kernel_tag` from the committed rocprofv3 PMC summary (profiles/pmc_traffic.json) - only
-    if that summary was collected from the kernel sources that are running now (their hash is stored with it).
+    HBM bytes per launch of `kernel_tag` in `workload` from the committed rocprofv3 PMC summary
+    (profiles/pmc_traffic.json: {workload: {kernel: ...}}) - only if that summary was collected from the kernel sources
+    that are running now (their hash is stored with it).
     """
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
@@ -143,7 +151,11 @@ def load_pmc_traffic(kernel_tag):
     sha = rec.get("_kernel_sources_sha256_16")
     if sha != kernel_sources_sha():
         return None, f"profiles/pmc_traffic.json was collected from other kernel sources ({sha}); re-run scripts/pmc.sh"
-    v = rec.get(kernel_tag, {}).get("hbm_bytes_per_launch")
+    want = canonical_kernel_name(kernel_tag)
+    per_workload = rec.get(workload)
+    if not isinstance(per_workload, dict):
+        return None, f"no PMC passes of workload {workload!r} in profiles/pmc_traffic.json"
+    v = next((e.get("hbm_bytes_per_launch") for k, e in per_workload.items() if canonical_kernel_name(k) == want), None)
     return v, (None if v is not None else "kernel not in profiles/pmc_traffic.json")
 
 
@@ -400,13 +412,17 @@ def main():
             L["flops_executed"] = float(round(L["flops_executed"]))
             L["TFLOPs"] = round(L["flops_executed"] / (L["ms"] * 1e-3) / 1e12, 2) if L["ms"] > 0 else None
             L["valu_frac"] = round(L["TFLOPs"] / VALU_PEAK_TFLOPS, 4) if L["TFLOPs"] else None
-            L["traffic"], note = load_pmc_traffic(L["kernel"])
+            L["traffic"], note = load_pmc_traffic(L["kernel"], args.workload)
+            if L["traffic"] and sum(M["kernel"] == L["kernel"] for M in launches) > 1:
+                # the counters are averaged per kernel NAME: a kernel that serves several launch groups of one step
+                # (the default plan's three band-limited groups) has no per-group figure
+                L["traffic"], note = None, "kernel serves several launch groups of this step: PMC average not attributable"
             L["traffic_ratio"] = round(L["traffic"] / L["algo_bytes"], 3) if L["traffic"] else None
             if note:
                 L["traffic_note"] = note
             L["ms"] = round(L["ms"], 4)
         dom = max(launches, key=lambda L: L["ms"])
-        traffic, traffic_note = load_pmc_traffic(dom["kernel"])
+        traffic, traffic_note = dom["traffic"], dom.get("traffic_note")
         kernel_ms = float(band_ms.sum())
         flops_per_sample = 50.0 * sum(np.log2(n) for n in sizes) + 80.0 * n_bands
         flops_executed = sum(L["flops_executed"] for L in launches)

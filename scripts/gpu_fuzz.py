@@ -10,12 +10,17 @@ def rms(a): return float(np.sqrt(np.mean(np.square(a)))) if a.size else 0.0
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 sizes = [64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536]
 overlaps = [0.5, 0.75, 0.875, 0.6, 0.7, 0.9, 0.75, 0.75]
+LIVE = len(sys.argv) > 3 and sys.argv[3] == "live"   # aim at the live-slot flavours: fused sizes, hop N/4, narrow bands
+if LIVE:
+    sizes, overlaps = [1024, 2048, 1024, 2048, 256, 512], [0.75]
 windows = sorted(ux.WINDOW_FUNCS)
 worst = 0.0
 t0 = time.time()
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     n_bands = int(rng.integers(1, 6))
     edges = np.sort(rng.uniform(10.0, 20000.0, size=n_bands + 1))
+    if LIVE:
+        edges = np.sort(rng.uniform(10.0, 9000.0, size=n_bands + 1))
     overlap = overlaps[int(rng.integers(len(overlaps)))]
     wname = windows[int(rng.integers(len(windows)))]
     mode = ["raised_cosine", "hard_zero"][int(rng.integers(2))]
@@ -50,5 +55,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     bad = any((not np.all(np.isfinite(g))) for g in got)
     worst = max(worst, max(errs))
     flag = "BAD" if (bad or max(errs) > 1e-5) else "ok"
-    print(f"{trial:3d} {flag} N={[b.block_size for b in gb]} ov={overlap} {wname} {mode} T={total} err={max(errs):.2e}", flush=True)
+    kn = ""
+    if LIVE:
+        q = ux.DevicePlan(gb)
+        kn = " " + ",".join(q.band_kernel_name(i).split("Live<")[-1].rstrip(">") if "Live<" in q.band_kernel_name(i) else "-" for i in range(len(gb)))
+        q.close()
+    print(f"{trial:3d} {flag} N={[b.block_size for b in gb]} ov={overlap} {wname} {mode} T={total} err={max(errs):.2e}{kn}", flush=True)
 print("worst", worst, "elapsed", time.time() - t0)

@@ -1,20 +1,17 @@
-"""One-GPU check of what the N > 1 bench / multi_gpu processes do in ONE process: torch (its bundled ROCm runtime) imported and a
-gloo group initialised FIRST, then libupmix_hip.so (system ROCm) with an RCCL communicator obtained through dlopen.  Prints which
-librccl / libamdhip64 files are mapped and runs the seam self-test (pack -> ncclAllReduce -> add) plus one band plan.
-Usage (GPU box): python scripts/rccl_with_torch_check.py"""
+"""One-GPU check of what a rank of an N > 1 run does, in ONE process and WITHOUT torch: the process group of
+upmix_amd.rendezvous (world 1 here), libupmix_hip.so with an RCCL communicator obtained through dlopen, the seam self-test
+(pack -> ncclAllReduce -> add) and one band plan; prints which librccl / libamdhip64 files are mapped (one of each:
+the process holds ONE HIP runtime) and leaves through a normal interpreter exit.
+Usage (GPU box): python scripts/rccl_rank_check.py"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ.setdefault("MASTER_PORT", "29611")
 import numpy as np
-import torch
-import torch.distributed as dist
 
-dist.init_process_group(backend="gloo", rank=0, world_size=1)
 import upmix_amd as ux
 from upmix_amd import sharding
+from upmix_amd.rendezvous import Rendezvous
 from oracle import upmix_oracle as orc
 
 
@@ -22,11 +19,13 @@ def mapped(pattern):
     return sorted({l.split()[-1] for l in open("/proc/self/maps") if pattern in l})
 
 
+group = Rendezvous.from_env()
 bands = ux.chain_bands([0, 300, 3000], 0.75, ux.make_blackman_harris, 48000, max_block_size=1024, verbose=False, device=0)
 plan = ux.DevicePlan(bands, device=0)
-seam = sharding.RcclSeam(plan, 0, 1, broadcast=lambda b: sharding.broadcast_bytes_gloo(dist, b))
+seam = sharding.RcclSeam(plan, group.rank, group.world, broadcast=group.broadcast_bytes)
 print("librccl mapped:", mapped("librccl"))
 print("libamdhip64 mapped:", mapped("libamdhip64"))
+print("torch imported:", "torch" in sys.modules)
 own, spill = 50000, 6144
 rng = np.random.default_rng(5)
 host = [rng.standard_normal(own + spill).astype(np.float32) for _ in range(3)]
@@ -48,8 +47,11 @@ outs = plan.process(x)
 ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64),
                              orc.plan_bands([0, 300, 3000], 0.75, orc.win_blackman_harris, 48000, max_block_size=1024))
 err = max(float(np.sqrt(np.mean((o.astype(np.float64) - r) ** 2))) for o, r in zip(outs, ref))
-t = torch.tensor([1.0], dtype=torch.float64)
-dist.all_reduce(t, op=dist.ReduceOp.MAX)
+print("max over ranks:", group.allreduce_max([1.0]))
 print("seam self-test", "ok" if ok else "FAILED", " band plan rms err %.2e" % err)
-sys.stdout.flush()
-os._exit(0 if ok and err < 1e-6 else 1)
+for p in d:
+    plan.free(p)
+seam.close()
+plan.close()
+group.close()
+sys.exit(0 if ok and err < 1e-6 else 1)

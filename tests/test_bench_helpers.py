@@ -14,7 +14,7 @@ def test_pmc_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(root))
     v, note = bench.load_pmc_traffic("k")
     assert v is None and "no profiles" in note
-    rec = {"k": {"hbm_bytes_per_launch": 123}, "_kernel_sources_sha256_16": "0" * 16}
+    rec = {"c3": {"k": {"hbm_bytes_per_launch": 123}}, "_kernel_sources_sha256_16": "0" * 16}
     (root / "profiles" / "pmc_traffic.json").write_text(json.dumps(rec))
     monkeypatch.setattr(bench, "kernel_sources_sha", lambda: sha)
     v, note = bench.load_pmc_traffic("k")
@@ -24,17 +24,23 @@ def test_pmc_traffic_is_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     assert bench.load_pmc_traffic("k") == (123, None)
     v, note = bench.load_pmc_traffic("other")
     assert v is None and "not in" in note
+    v, note = bench.load_pmc_traffic("k", "batch")                  # counters of another workload do not transfer
+    assert v is None and "no PMC passes of workload" in note
 
 
 def test_committed_pmc_summary_names_every_c3_kernel():
     """The committed summary must carry the kernels the recorded workload launches (names as bench.py reports them)."""
     rec = json.load(open(os.path.join(os.path.dirname(bench.__file__), "profiles", "pmc_traffic.json")))
-    names = " ".join(rec)
-    for k in ("upx_zoom_analysis_kernel<upx::ZoomCfg<8, 16, 4>", "upx_zoom_synthesis_kernel<upx::ZoomCfg<9, 8, 4>",
-              "upx_band_kernel<upx::Cfg<10, 4, 16>, 2, false>", "upx_band_kernel<upx::Cfg<8, 4, 16>, 2, false>",
-              "upx_big_mid_kernel<upx::BigCfg<16>, 2>"):
-        assert k in names, k
-    assert all(v["hbm_bytes_per_launch"] > 0 for k, v in rec.items() if not k.startswith("_"))
+    assert all(w in rec for w in ("c3", "c4share", "default"))
+    names = {bench.canonical_kernel_name(k) for w in ("c3", "c4share") for k in rec[w]}
+    for k in ("upx_zoom_analysis_kernel<upx::ZoomCfg<8, 16, 4>>", "upx_zoom_synthesis_kernel<upx::ZoomCfg<9, 8, 4>>",
+              "upx_band_kernel<upx::Cfg<10, 4, 16>, 2, false, upx::Live<0, 4>>", "upx_band_kernel<upx::Cfg<8, 4, 16>, 2, false>",
+              "upx_band_kernel<upx::Cfg<11, 4, 16>, 2, false, upx::Live<0, 2>>", "upx_zoom_synthesis_kernel<upx::ZoomCfg<9, 16, 4>>"):
+        assert bench.canonical_kernel_name(k) in names, k
+    # rocprofv3's spelling of the general flavour and the library's own name meet
+    assert bench.canonical_kernel_name("void upxk::upx_band_kernel<upx::Cfg<8, 4, 16>, 2, false, upx::Live<0, 1048576> >") == \
+        bench.canonical_kernel_name("upx_band_kernel<upx::Cfg<8, 4, 16>, 2, false>")
+    assert all(v["hbm_bytes_per_launch"] > 0 for w, e in rec.items() if not w.startswith("_") for v in e.values())
 
 
 def test_workload_table():

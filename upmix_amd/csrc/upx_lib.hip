@@ -975,22 +975,32 @@ int run_items(upx_plan* p, const std::vector<PipeItem>& items) {
         if (it.t_out > cap_out) cap_out = it.t_out;
     }
     const size_t in_floats = (size_t)cap_in * 2, out_floats = (size_t)cap_out * 3;
-    if (in_floats > p->pipe_in_floats || out_floats > p->pipe_out_floats) {
+    // two rotating buffer sets, grown on demand and never shrunk; a call with ONE work item (a short signal, or
+    // UPX_STREAM_CHUNK=0) only touches - and only ever allocates - the first.  Both sets share one plane pitch.
+    const int n_sets = items.size() > 1 ? 2 : 1;
+    bool grow = in_floats > p->pipe_in_floats || out_floats > p->pipe_out_floats;
+    for (int i = 0; i < n_sets; ++i) grow |= !p->d_pipe_in[i] || !p->d_pipe_out[i];
+    if (grow) {
         HIP_TRY(hipDeviceSynchronize());
+        const size_t want_in = in_floats > p->pipe_in_floats ? in_floats : p->pipe_in_floats;
+        const size_t want_out = out_floats > p->pipe_out_floats ? out_floats : p->pipe_out_floats;
+        const bool resize = want_in != p->pipe_in_floats || want_out != p->pipe_out_floats;
         for (int i = 0; i < 2; ++i) {
+            const bool have = p->d_pipe_in[i] && p->d_pipe_out[i];
+            if (have && !resize) continue;
             if (p->d_pipe_in[i]) HIP_TRY(hipFree(p->d_pipe_in[i]));
             if (p->d_pipe_out[i]) HIP_TRY(hipFree(p->d_pipe_out[i]));
             p->d_pipe_in[i] = p->d_pipe_out[i] = nullptr;
-        }
-        p->pipe_in_floats = p->pipe_out_floats = 0;
-        const size_t want_in = in_floats > p->pipe_in_floats ? in_floats : p->pipe_in_floats;
-        for (int i = 0; i < 2; ++i) {
-            hipError_t e = hipMalloc(&p->d_pipe_in[i], want_in * sizeof(float));
-            if (e == hipSuccess) e = hipMalloc(&p->d_pipe_out[i], out_floats * sizeof(float));
-            if (e != hipSuccess) return fail(UPX_ERR_NOMEM, "hipMalloc for a %lld-sample work item: %s", (long long)cap_out, hipGetErrorString(e));
+            if (i >= n_sets && !have) continue;   // a second set that has never been needed stays unallocated
+            hipError_t e = hipMalloc(&p->d_pipe_in[i], (want_in ? want_in : 2) * sizeof(float));
+            if (e == hipSuccess) e = hipMalloc(&p->d_pipe_out[i], (want_out ? want_out : 3) * sizeof(float));
+            if (e != hipSuccess) {
+                p->pipe_in_floats = p->pipe_out_floats = 0;
+                return fail(UPX_ERR_NOMEM, "hipMalloc for a %lld-sample work item: %s", (long long)cap_out, hipGetErrorString(e));
+            }
         }
         p->pipe_in_floats = want_in;
-        p->pipe_out_floats = out_floats;
+        p->pipe_out_floats = want_out;
     }
     const size_t plane = p->pipe_out_floats / 3;
 #if defined(UPX_TEST_HOOKS)   // never in the product library: a test build fails the download of this item
