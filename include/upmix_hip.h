@@ -202,6 +202,11 @@ int upx_wav_pipeline(upx_plan* plan, const void* pcm_in, int in_format, int chan
 int upx_wav_shard_begin(upx_plan* plan, upx_comm* comm, const void* pcm_in, int in_format, int channels, int64_t t_in,
                         int64_t own_len, int64_t t_out, int64_t spill, double* peaks);
 int upx_wav_shard_finish(upx_plan* plan, double scale, int mode, int out_format, void* out0, void* out1, void* out2);
+/* Between begin and finish: the device planes of the open shard (plane length t_out, the first own_len samples owned) - for
+   a seam applied by the caller (upx_seam_add_local between two shards on one device: long files on one GPU, and the
+   one-GPU test of the sharded pipeline) - and the peaks of the owned range recomputed after such a seam. */
+int upx_wav_shard_planes(upx_plan* plan, float** d_c, float** d_l, float** d_r, int64_t* own_len, int64_t* t_out);
+int upx_wav_shard_peaks(upx_plan* plan, double* peaks);
 /* Milliseconds spent in the last upx_wav_pipeline call: H2D, decode+kernels+peak+export, D2H. */
 int upx_wav_pipeline_times_ms(upx_plan* plan, float* ms3);
 

@@ -337,7 +337,48 @@ def test_device_helpers_absmax_scale(ux, orc):
     back = np.empty_like(v)
     plan.d2h(back, d)
     assert np.array_equal(back, v * np.float32(0.5))
+    # np.max(np.abs(.)) semantics (main.py:53, :85-88): a NaN anywhere gives NaN, an infinity wins over every number
+    for bad, want in ((np.nan, "nan"), (-np.inf, "inf")):
+        w = v.copy()
+        w[77777] = bad
+        plan.h2d(d, w)
+        got = plan.absmax(d, len(w))
+        assert (np.isnan(got) if want == "nan" else got == np.inf), (bad, got)
     plan.free(d)
+    plan.close()
+
+
+def test_results_live_in_pooled_page_locked_memory(ux, orc, monkeypatch):
+    """DevicePlan.process returns NEW arrays per call (the reference returns fresh NumPy arrays, center_extraction.py:503-513)
+    that live in pooled page-locked blocks (upmix_amd/hostmem.py): a block is reused only after every array on it is gone,
+    results stay intact while held, and beyond the pool's limit the arrays are plain pageable ones - same numbers."""
+    import gc
+    from upmix_amd import hostmem
+    bands = gpu_chain(ux, [0, 300, 3000], 48000, 4096, 64)
+    plan = ux.DevicePlan(bands)
+    x = orc.synthetic_stereo(300000, 21)
+    y = orc.synthetic_stereo(300000, 22)
+    a = plan.process(x)
+    keep = [o.copy() for o in a]
+    b = plan.process(y)                                # `a` is still held: `b` must not land on its blocks
+    assert all(np.array_equal(o, k) for o, k in zip(a, keep))
+    assert not any(np.shares_memory(o, q) for o in a for q in b)
+    addr = {o.ctypes.data for o in a}
+    view = a[0][1000:2000]                             # a view keeps its block alive
+    del a
+    gc.collect()
+    c = plan.process(x)                                # the freed blocks come back (two of them: one is still viewed)
+    assert len(addr & {o.ctypes.data for o in c}) == 2
+    assert np.array_equal(view, keep[0][1000:2000]) and all(np.array_equal(o, k) for o, k in zip(c, keep))
+    held = hostmem.POOL._held
+    assert held >= 8 * 300000 * 4                      # at least the eight live planes are pinned
+    # a pool without room hands out pageable arrays; the numbers do not change
+    monkeypatch.setattr(hostmem.POOL, "limit", 0)
+    d = plan.process(x)
+    assert all(np.array_equal(o, k) for o, k in zip(d, keep)) and hostmem.POOL._held == held
+    left = c[1]
+    left *= 2.0                                        # results are the caller's to scale in place (main.py:95-97)
+    assert np.array_equal(c[1], keep[1] * np.float32(2.0))
     plan.close()
 
 

@@ -216,3 +216,56 @@ def test_multi_gpu_entry_world_one_equals_cli(tmp_path, monkeypatch, capsys):
             other = os.path.join(tmp, "out_mg_host", os.path.basename(path))
             assert open(path, "rb").read() == open(other, "rb").read(), (mode, key)
     capsys.readouterr()
+
+
+@pytest.mark.gpu
+def test_sharded_device_pipeline_two_shards_on_one_gpu(tmp_path):
+    """What two ranks do with upx_wav_shard_begin / _finish, on ONE device: a plan per shard, each fed only its own bytes
+    (+ halo), the overlap-add seam through upx_seam_add_local in the place of the RCCL all-reduce (same algebra,
+    tests/test_sharding.py), the peaks maxed over the shards, one global scale.  The assembled payload is the payload of
+    the whole-file pipeline except for <= 1 LSB on a few samples behind the seams (the shard's and the kernels' own)."""
+    import upmix_amd as ux
+    from upmix_amd import _lib
+    tmp = str(tmp_path)
+    path = os.path.join(tmp, "song.wav")
+    make_wav(path, total=400000, seed=77, subtype="PCM_24")
+    meta = wav.info(path)
+    total, kind = meta["n_frames"], wav.device_kind(meta)
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 48000, max_block_size=8192,
+                           verbose=False)
+    geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
+    shards = geo.plan(total, 2)
+    assert geo.spill == 6144 and shards[1].start % (2 * 2048) == 0
+    whole = ux.DevicePlan(bands)
+    plans = [ux.DevicePlan(bands) for _ in shards]
+    try:
+        for mode, out_kind, dt in (("stereo_sum", 16, "<i2"), ("split", 32, "<i4"), ("AB", 16, "<i2")):
+            ref, ref_stats = whole.wav_pipeline(wav.read_raw_range(path, 0, total, meta), kind, 2, total, mode, out_kind)
+            peaks = []
+            for sh, plan in zip(shards, plans):
+                raw = wav.read_raw_range(path, sh.start, sh.t_in, meta)            # this shard's bytes and nothing else
+                t_out = sh.own_len + (0 if sh.last else geo.spill)
+                plan.wav_shard_begin(raw, kind, 2, sh.t_in, sh.own_len, t_out, geo.spill, None)
+            plans[1].seam_add_local(plans[0].wav_shard_planes(), shards[0].own_len, plans[1].wav_shard_planes(), geo.spill)
+            plans[1].sync()
+            peaks = [p.wav_shard_peaks() for p in plans]
+            pin, pout = max(p[0] for p in peaks), max(p[1] for p in peaks)
+            assert abs(pin - ref_stats["peak_in"]) < 1e-12 and abs(pout - ref_stats["overall_peak"]) < 1e-6
+            scale = float(np.float64(pin) / np.float64(max(pout, 1e-9)))
+            parts = [p.wav_shard_finish(scale, mode, out_kind, sh.own_len) for sh, p in zip(shards, plans)]
+            for key in ref:
+                got = np.concatenate([np.frombuffer(bytes(part[key]), dtype=dt) for part in parts]).astype(np.int64)
+                want = np.frombuffer(bytes(ref[key]), dtype=dt).astype(np.int64)
+                assert got.shape == want.shape
+                diff = np.nonzero(got != want)[0] // 2
+                lsb = 1 if out_kind == 16 else 1 << 17      # the seam's float32 association: ~1e-7 of full scale
+                assert np.max(np.abs(got - want), initial=0) <= lsb, (mode, key)
+                # (differences sit behind the shard seam and behind the kernels' own stream seams, which a shorter
+                # launch cuts elsewhere: float32 association of the overlap-add, DESIGN.md 2) - a handful of samples
+                # (at 32 bits every float32 rounding difference in a seam region is visible: a few per cent of the samples)
+                assert len(diff) <= got.size // (2000 if out_kind == 16 else 10), (mode, key, len(diff))
+        with pytest.raises(ValueError):
+            plans[0].wav_shard_finish(1.0, "stereo_sum", 16, 10)                    # no shard open any more
+    finally:
+        for p in plans + [whole]:
+            p.close()

@@ -67,6 +67,8 @@ SIGNATURES = {
     "upx_wav_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                       C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
     "upx_wav_shard_finish": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "upx_wav_shard_planes": (C.c_int, [C.c_void_p, vpp, vpp, vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "upx_wav_shard_peaks": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "upx_wav_pipeline_times_ms": (C.c_int, [C.c_void_p, f32p]),
     "upx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "upx_comm_create": (C.c_int, [vpp, C.c_void_p, C.c_int, C.c_int, C.c_char_p]),

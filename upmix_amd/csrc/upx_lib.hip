@@ -1332,17 +1332,36 @@ int upx_wav_shard_begin(upx_plan* p, upx_comm* comm, const void* pcm_in, int in_
     if (int rc = upx_process_device(p, d_st, t_in, own_len, d_pl, d_pl + t_out, d_pl + 2 * t_out, t_out)) return rc;
     if (exchange)
         if (int rc = upx_comm_seam_exchange(comm, d_pl, d_pl + t_out, d_pl + 2 * t_out, own_len, spill)) return rc;
-    // peaks of the owned range: the input (both channels) and the three planes (main.py:53-55, :85-88)
-    float pk[4] = {0.f, 0.f, 0.f, 0.f};
-    if (int rc = upx_absmax(p, d_st, 2 * own_len, &pk[0])) return rc;
-    for (int i = 0; i < 3; ++i)
-        if (int rc = upx_absmax(p, d_pl + (size_t)i * t_out, own_len, &pk[1 + i])) return rc;
-    auto fmax_nan = [](float a, float b) { return (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b); };
-    peaks[0] = (double)pk[0];
-    peaks[1] = (double)fmax_nan(fmax_nan(pk[1], pk[2]), pk[3]);
     p->wav_tin = t_in; p->wav_own = own_len; p->wav_tout = t_out;
     p->wav_fmt = in_format; p->wav_ch = channels;
     p->wav_open = true;
+    return upx_wav_shard_peaks(p, peaks);
+}
+
+int upx_wav_shard_peaks(upx_plan* p, double* peaks) {
+    if (!p || !peaks || !p->wav_open) return fail(UPX_ERR_INVALID, "upx_wav_shard_peaks: no shard is open");
+    HIP_TRY(hipSetDevice(p->device));
+    // peaks of the owned range: the input (both channels) and the three planes (main.py:53-55, :85-88)
+    const float* d_st = (const float*)p->d_wav[1];
+    const float* d_pl = (const float*)p->d_wav[2];
+    float pk[4] = {0.f, 0.f, 0.f, 0.f};
+    if (int rc = upx_absmax(p, d_st, 2 * p->wav_own, &pk[0])) return rc;
+    for (int i = 0; i < 3; ++i)
+        if (int rc = upx_absmax(p, d_pl + (size_t)i * p->wav_tout, p->wav_own, &pk[1 + i])) return rc;
+    auto fmax_nan = [](float a, float b) { return (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b); };
+    peaks[0] = (double)pk[0];
+    peaks[1] = (double)fmax_nan(fmax_nan(pk[1], pk[2]), pk[3]);
+    return UPX_OK;
+}
+
+int upx_wav_shard_planes(upx_plan* p, float** d_c, float** d_l, float** d_r, int64_t* own_len, int64_t* t_out) {
+    if (!p || !p->wav_open) return fail(UPX_ERR_INVALID, "upx_wav_shard_planes: no shard is open");
+    float* d_pl = (float*)p->d_wav[2];
+    if (d_c) *d_c = d_pl;
+    if (d_l) *d_l = d_pl + p->wav_tout;
+    if (d_r) *d_r = d_pl + 2 * p->wav_tout;
+    if (own_len) *own_len = p->wav_own;
+    if (t_out) *t_out = p->wav_tout;
     return UPX_OK;
 }
 

@@ -245,6 +245,18 @@ class DevicePlan:
                                                      int(t_in), int(own_len), int(t_out), int(spill), peaks))
         return float(peaks[0]), float(peaks[1])
 
+    def wav_shard_planes(self):
+        """Device pointers (center, left, right) of the open shard's planes, for a seam applied by the caller."""
+        ptrs = [C.c_void_p() for _ in range(3)]
+        _lib.check(self._lib.upx_wav_shard_planes(self.handle, *(C.byref(q) for q in ptrs), None, None))
+        return [q.value for q in ptrs]
+
+    def wav_shard_peaks(self):
+        """(peak_in, peak_out) of the open shard's owned range, recomputed (after a caller-applied seam)."""
+        peaks = (C.c_double * 2)()
+        _lib.check(self._lib.upx_wav_shard_peaks(self.handle, peaks))
+        return float(peaks[0]), float(peaks[1])
+
     def wav_shard_finish(self, scale: float, mode: str, out_format: int, n_frames: int):
         """Second half: scale, export layout, quantisation on the device; -> {name: uint8 payload of n_frames frames}."""
         if mode not in self._MODES:
