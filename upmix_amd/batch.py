@@ -145,7 +145,7 @@ def main(argv=None) -> int:
                         names = export.export_file_names(os.path.splitext(os.path.basename(paths[i]))[0], a.export_mode,
                                                          bands, a.overlap)
                         outs = [os.path.join(a.out_dir, names[k]) for k in payloads]
-                        jobs = [lambda p=p, b=b: wav.write_raw(p, b, sr, _SUBTYPE_KIND[a.subtype], 2)
+                        jobs = [lambda p=p, b=b, sr=sr: wav.write_raw(p, b, sr, _SUBTYPE_KIND[a.subtype], 2)
                                 for p, b in zip(outs, payloads.values())]
                     else:
                         if pos + 1 < len(group) and on_device(group[pos + 1]) and ahead is None:

@@ -190,6 +190,7 @@ struct BandState {
     const KernelEntry* kern = nullptr;
     const BigEntry* big = nullptr;      // STFT > 8192: four-step path
     const ZoomEntry* zoom = nullptr;    // band-limited group: pruned analysis + residue-stream synthesis (upx_zoom.h)
+    const ZoomEntry* zoom_a = nullptr;  // the entry whose ANALYSIS kernel runs (may hold fewer residues per workgroup)
     int zoom_p = 0, zoom_d = 0;         // decimated frame length P, decimation D = N / P
     upx::cf* d_ramp = nullptr;          // ramp seeds [D][P/16 + 4] (upx::zoom_ramp)
     int kmax = 0;                       // highest bin with non-zero gain (leader: over the whole group)
@@ -313,8 +314,9 @@ int zoom_frames_cap(const upx_plan* p, int zp) {
 }
 // workgroups of the band-limited kernels one CU holds (waves per SIMD by registers; LDS: 160 KB)
 int zoom_resident(const BandState& s, bool analysis = false) {
-    const int wpe = analysis ? s.zoom->wpe_a : s.zoom->wpe, lds = analysis ? s.zoom->lds_bytes_a : s.zoom->lds_bytes;
-    int by_waves = (wpe * 256) / s.zoom->wg;
+    const ZoomEntry* z = analysis ? s.zoom_a : s.zoom;
+    const int wpe = analysis ? z->wpe_a : z->wpe, lds = analysis ? z->lds_bytes_a : z->lds_bytes;
+    int by_waves = (wpe * 256) / z->wg;
     const int by_lds = (160 * 1024) / lds;
     if (by_waves > by_lds) by_waves = by_lds;
     return by_waves < 1 ? 1 : by_waves;
@@ -464,15 +466,30 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                 if (s.zoom) {
                     s.zoom_p = zp;
                     s.zoom_d = d;
+                    // The spectra between the two kernels do not depend on how many residues a workgroup holds, so the
+                    // analysis need not use the synthesis' 16.  At P >= 512 sixteen residues are a workgroup of 8 or 16 waves
+                    // at 128 VGPRs without the input prefetch; eight residues (4 or 8 waves, 168 VGPRs, prefetching, two
+                    // groups per frame) measured 0.664 -> 0.593 ms on C4's main group (N = 8192, P = 512) and -5 % on the
+                    // default plan's 65 536 / 16 384 bands; at P = 256 sixteen stay (+3 % with eight).  UPX_ZOOM_A_RG overrides.
+                    s.zoom_a = s.zoom;
+                    const char* e = std::getenv("UPX_ZOOM_A_RG");
+                    const int rg_a = e ? std::atoi(e) : (zp >= 512 ? 8 : s.zoom->rg);
+                    if (rg_a != s.zoom->rg) {
+                        const ZoomEntry* alt = find_zoom(ilog2_exact(zp), rg_a, s.k);
+                        if (alt && d % alt->rg == 0) s.zoom_a = alt;
+                    }
                 }
             }
         }
         if (!s.zoom && std_hop && !force_unfused) s.kern = find_kernel(s.log2n, s.n / s.hop, default_variant());
         if (!s.zoom && !s.kern) s.big = find_big(s.log2n);
+        if (s.zoom && s.zoom_a != s.zoom)
+            if (int e = s.zoom_a->prepare())
+                return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
         if (int e = s.zoom ? s.zoom->prepare() : (s.kern ? s.kern->prepare() : s.big->prepare()))
             return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
         for (int m = b + 1; m < b + s.group_size; ++m) {   // members: only for reporting
-            p->bands[m].zoom = s.zoom; p->bands[m].kern = s.kern; p->bands[m].big = s.big;
+            p->bands[m].zoom = s.zoom; p->bands[m].zoom_a = s.zoom_a; p->bands[m].kern = s.kern; p->bands[m].big = s.big;
             p->bands[m].zoom_p = s.zoom_p; p->bands[m].zoom_d = s.zoom_d;
         }
     }
@@ -823,7 +840,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                 if (per_xcd < 1) per_xcd = 1;
                 a.pairs_per_wg = (int)per_xcd;
                 if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
-                s.zoom->analysis(a, (int)(8 * per_xcd), p->stream);
+                s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
                 if (split) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
                 s.zoom->synthesis(a, (int)ns, groups, p->stream);
             }
@@ -1200,7 +1217,7 @@ int upx_plan_band_phase_kernel_name(upx_plan* p, int band, int phase, char* name
     if (!p || !name || n == 0 || band < 0 || band >= (int)p->bands.size() || phase < 0 || phase > 1)
         return fail(UPX_ERR_INVALID, "upx_plan_band_phase_kernel_name: bad argument");
     const BandState& s = p->bands[p->bands[band].group_leader];
-    if (s.zoom) std::snprintf(name, n, "%s", phase == 0 ? s.zoom->name_analysis : s.zoom->name_synthesis);
+    if (s.zoom) std::snprintf(name, n, "%s", phase == 0 ? s.zoom_a->name_analysis : s.zoom->name_synthesis);
     else if (phase == 0) name[0] = 0;   // single-kernel bands have no separate analysis phase
     else if (s.kern) std::snprintf(name, n, "%s", s.kern->name);
     else std::snprintf(name, n, "unfused<%d>", s.n);
