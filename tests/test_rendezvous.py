@@ -98,3 +98,46 @@ def test_product_path_does_not_import_torch():
     for path in files:
         text = open(path).read()
         assert "import torch" not in text and "os._exit" not in text, path
+
+
+def _join(rank, world, port, n_ports, q):
+    try:
+        with rendezvous.Rendezvous(rank, world, "127.0.0.1", port, timeout=60, n_ports=n_ports) as g:
+            q.put((rank, g.allreduce_max([float(rank)])[0]))
+    except Exception as exc:   # noqa: BLE001
+        q.put((rank, repr(exc)))
+
+
+@pytest.mark.timeout(120)
+def test_busy_port_is_stepped_over():
+    """The first candidate port is held by a foreign service that answers nonsense: rank 0 listens on the next one and
+    the other rank finds it there."""
+    import threading
+    foreign = socket.socket()
+    foreign.bind(("127.0.0.1", 0))
+    foreign.listen(4)
+    port = foreign.getsockname()[1]
+    stop = threading.Event()
+
+    def serve():
+        foreign.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = foreign.accept()
+                c.sendall(b"HTTP/1.0 400\r\n\r\n")
+                c.close()
+            except OSError:
+                pass
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_join, args=(r, 2, port, 4, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=90) for _ in range(2))
+    for p in procs:
+        p.join(30)
+    stop.set()
+    foreign.close()
+    assert got == [(0, 1.0), (1, 1.0)], got

@@ -9,7 +9,10 @@ one message down.  No torch: a process that runs the kernels maps ONE HIP runtim
 
 Address: the launcher's MASTER_ADDR / MASTER_PORT (torch.distributed.run, or any launcher that exports RANK,
 WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  torch.distributed.run keeps its own store on MASTER_PORT (it says so with
-TORCHELASTIC_USE_AGENT_STORE=True), so the star then uses MASTER_PORT + 1; UPX_RDZV_PORT overrides.
+TORCHELASTIC_USE_AGENT_STORE=True), so the star then starts at MASTER_PORT + 1.  Should that port be taken, rank 0
+listens on the next free one of the following seven and the other ranks find it by trying the same eight in turn (the
+hello carries a magic word, the rank and the world size, so a foreign service is recognised and skipped).
+UPX_RDZV_PORT pins one port.
 The reference has no counterpart: its only parallelism is a thread pool (center_extraction.py:499-501).
 """
 from __future__ import annotations
@@ -64,7 +67,9 @@ class Rendezvous:
     world == 1 needs no socket.
     """
 
-    def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29500, timeout: float = 600.0):
+    def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29500, timeout: float = 600.0,
+                 n_ports: int = 1):
+        """`port` .. `port + n_ports - 1`: rank 0 listens on the first one it can bind, the others try them in turn."""
         if world < 1 or not 0 <= rank < world:
             raise ValueError(f"rank {rank} of {world}")
         self.rank, self.world = int(rank), int(world)
@@ -75,13 +80,19 @@ class Rendezvous:
             return
         deadline = time.monotonic() + timeout
         if rank == 0:
-            ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                ls.bind(("127.0.0.1" if addr in ("127.0.0.1", "localhost", "") else "", port))
-            except OSError as exc:
-                ls.close()
-                raise RendezvousError(f"rank 0 cannot listen on {addr}:{port} ({exc}); set UPX_RDZV_PORT") from exc
+            ls, last = None, None
+            for cand in range(port, port + max(1, n_ports)):
+                ls = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    ls.bind(("127.0.0.1" if addr in ("127.0.0.1", "localhost", "") else "", cand))
+                    break
+                except OSError as exc:
+                    ls.close()
+                    ls, last = None, exc
+            if ls is None:
+                raise RendezvousError(f"rank 0 cannot listen on {addr}:{port}..{port + max(1, n_ports) - 1} ({last}); "
+                                      "set UPX_RDZV_PORT") from last
             ls.listen(world)
             self._listener = ls
             self._peers = [None] * world
@@ -109,20 +120,28 @@ class Rendezvous:
                 missing -= 1
         else:
             last: Optional[BaseException] = None
+            attempt = 0
             while True:
+                cand = port + attempt % max(1, n_ports)
+                attempt += 1
+                s = None
                 try:
-                    s = socket.create_connection((addr, port), timeout=min(5.0, max(0.1, deadline - time.monotonic())))
-                    s.settimeout(timeout)
+                    s = socket.create_connection((addr, cand), timeout=min(5.0, max(0.1, deadline - time.monotonic())))
+                    s.settimeout(min(timeout, 10.0))          # a foreign service that never answers is given up on
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     s.sendall(_MAGIC + struct.pack("<ii", rank, world))
                     if _recv_exact(s, len(_MAGIC)) != _MAGIC:
                         raise RendezvousError("unexpected reply")
+                    s.settimeout(timeout)
                     self._up = s
                     break
-                except (OSError, RendezvousError) as exc:   # rank 0 is not listening yet
+                except (OSError, RendezvousError) as exc:   # rank 0 is not listening (yet, or not on this port)
                     last = exc
+                    if s is not None:
+                        s.close()
                     if time.monotonic() > deadline:
-                        raise RendezvousError(f"rank {rank} cannot reach rank 0 at {addr}:{port}: {last}") from exc
+                        raise RendezvousError(f"rank {rank} cannot reach rank 0 at {addr}:{port}"
+                                              f"{'..' + str(port + n_ports - 1) if n_ports > 1 else ''}: {last}") from exc
                     time.sleep(0.05)
 
     # ---- construction from the launcher's environment ------------------------------------------------------
@@ -130,7 +149,8 @@ class Rendezvous:
     def from_env(cls, env=os.environ, timeout: Optional[float] = None) -> "Rendezvous":
         rank, world = int(env.get("RANK", "0")), int(env.get("WORLD_SIZE", "1"))
         t = float(env.get("UPX_RDZV_TIMEOUT", "600")) if timeout is None else timeout
-        return cls(rank, world, env.get("MASTER_ADDR", "127.0.0.1"), default_port(env), t)
+        return cls(rank, world, env.get("MASTER_ADDR", "127.0.0.1"), default_port(env), t,
+                   n_ports=1 if env.get("UPX_RDZV_PORT") else 8)
 
     # ---- the one primitive: everybody's bytes to everybody -----------------------------------------------------
     def allgather_bytes(self, payload: bytes) -> List[bytes]:
