@@ -1,0 +1,101 @@
+"""
+upmix_amd.hostmem (pool of page-locked result arrays) without a GPU: the library's two entry points are replaced by a
+stand-in that hands out ordinary memory, so the pool's bookkeeping runs on the CPU - a block is reused only after the
+last array or view on it has died, the limit falls back to pageable arrays, returned blocks never take the pool's
+lock (a finaliser may run inside take() on the same thread), trim releases idle blocks only.
+"""
+import ctypes as C
+import gc
+
+import numpy as np
+
+from upmix_amd import hostmem
+
+
+class FakeLib:
+    def __init__(self):
+        self.bufs, self.allocs, self.frees = {}, 0, 0
+
+    def upx_host_alloc(self, plan, pp, cap):
+        b = (C.c_ubyte * cap)()
+        self.bufs[C.addressof(b)] = b
+        pp._obj.value = C.addressof(b)
+        self.allocs += 1
+        return 0
+
+    def upx_host_free(self, plan, p):
+        self.bufs.pop(p.value)
+        self.frees += 1
+        return 0
+
+
+def make_pool(monkeypatch, limit):
+    fake = FakeLib()
+    monkeypatch.setattr(hostmem._lib, "load", lambda: fake)
+    return hostmem.PinnedPool(limit), fake
+
+
+def test_blocks_are_reused_only_when_every_view_is_gone(monkeypatch):
+    pool, fake = make_pool(monkeypatch, 64 << 20)
+    a = pool.take(1000, None)
+    assert a.dtype == np.uint8 and a.shape == (1000,) and a.flags.writeable
+    a[:] = 7
+    addr = a.ctypes.data
+    view = a[10:20].view(np.int16)
+    del a
+    gc.collect()
+    b = pool.take(1000, None)
+    assert b.ctypes.data != addr and view.tolist() == [0x0707] * 5      # the view keeps its block (and its bytes)
+    del view
+    gc.collect()
+    c = pool.take(900, None)                                             # same 2 MiB class: the freed block comes back
+    assert c.ctypes.data == addr and fake.allocs == 2
+    assert pool._held == 2 * hostmem._GRANULE
+
+
+def test_limit_falls_back_to_pageable_and_trim_releases_idle_blocks(monkeypatch):
+    g = hostmem._GRANULE
+    pool, fake = make_pool(monkeypatch, 4 * g)
+    a, b = pool.take(g, None), pool.take(g, None)
+    over = pool.take(3 * g, None)                                        # 2 + 3 > 4 granules: an ordinary array
+    assert fake.allocs == 2 and over.base is None and over.shape == (3 * g,)
+    del a
+    gc.collect()
+    big = pool.take(3 * g - 5, None)                                     # needs room: the idle block is released first
+    assert fake.frees == 1 and fake.allocs == 3 and pool._held == 4 * g and big.base is not None
+    c = pool.take(g, None)                                               # full again
+    assert c.base is None
+    del b
+    gc.collect()
+    pool.trim(None)
+    assert fake.frees == 2 and len(fake.bufs) == 1 and pool._held == 3 * g     # `big` is still held
+    assert big.sum() >= 0 and pool.take(0, None).size == 0
+
+
+def test_finaliser_inside_take_does_not_deadlock(monkeypatch):
+    """A lease that dies while take() holds the pool's lock (cyclic garbage collection can run at any allocation)."""
+    pool, fake = make_pool(monkeypatch, 64 << 20)
+    a = pool.take(100, None)
+    real_alloc = fake.upx_host_alloc
+
+    def alloc_and_drop(plan, pp, cap):
+        nonlocal a
+        a = None                          # the last reference goes away INSIDE take(), under its lock
+        gc.collect()
+        return real_alloc(plan, pp, cap)
+    fake.upx_host_alloc = alloc_and_drop
+    b = pool.take(5 * hostmem._GRANULE, None)      # another size class: allocates, and must return
+    assert b.size == 5 * hostmem._GRANULE
+    c = pool.take(100, None)                       # the block handed back inside take() is in the pool now
+    assert fake.allocs == 2 and c.size == 100
+
+
+def test_empty_gives_shaped_typed_arrays(monkeypatch):
+    fake = FakeLib()
+    monkeypatch.setattr(hostmem._lib, "load", lambda: fake)
+    monkeypatch.setattr(hostmem, "POOL", hostmem.PinnedPool(64 << 20))
+    x = hostmem.empty((1000, 2), np.float32, None)
+    assert x.shape == (1000, 2) and x.dtype == np.float32 and x.flags.c_contiguous
+    x[:] = 1.5
+    y = hostmem.empty(12, np.int16, None)
+    assert y.shape == (12,) and float(x.sum()) == 3000.0

@@ -13,6 +13,7 @@ The reference returns fresh NumPy arrays (center_extraction.py:503-513) that the
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 import threading
@@ -44,6 +45,9 @@ class PinnedPool:
     def __init__(self, limit_bytes: int):
         self.limit = int(limit_bytes)
         self._free: Dict[int, List[int]] = {}
+        # blocks handed back by dying arrays: a finaliser may run at ANY allocation point (cyclic garbage collection),
+        # also inside take() on the same thread, so it must not take the pool's lock: it only appends here (atomic)
+        self._returned: "collections.deque" = collections.deque()
         self._held = 0            # bytes pinned by this pool (free + leased)
         self._lock = threading.Lock()
         self._plan_handle = None  # any live upx_plan of the process (allocation needs a device context)
@@ -57,6 +61,7 @@ class PinnedPool:
         cap = -(-nbytes // _GRANULE) * _GRANULE
         lib = _lib.load()
         with self._lock:
+            self._collect()
             stack = self._free.get(cap)
             ptr = stack.pop() if stack else None
             if ptr is None:
@@ -78,16 +83,22 @@ class PinnedPool:
         return np.asarray(_Lease(self, ptr, cap, nbytes))
 
     def _give_back(self, ptr: int, cap: int) -> None:
-        with self._lock:
-            if not self.closed:
-                self._free.setdefault(cap, []).append(ptr)
+        self._returned.append((ptr, cap))   # (a closed pool keeps them: the runtime frees the blocks at unload)
+
+    def _collect(self) -> None:
+        """Move returned blocks to the free lists (call with the lock held)."""
+        while True:
+            try:
+                ptr, cap = self._returned.popleft()
+            except IndexError:
                 return
-        # the pool is closed (interpreter exit): the block stays with the process; the runtime frees it at unload
+            self._free.setdefault(cap, []).append(ptr)
 
     def trim(self, plan_handle) -> None:
         """Release every idle block (called when the last plan closes, while a device context still exists)."""
         lib = _lib.load()
         with self._lock:
+            self._collect()
             for cap, stack in self._free.items():
                 while stack:
                     lib.upx_host_free(plan_handle, C.c_void_p(stack.pop()))
