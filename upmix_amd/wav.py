@@ -174,6 +174,8 @@ def read_raw_range(path: str, start: int, count: int, meta: Optional[dict] = Non
     count = max(0, min(int(count), meta["n_frames"] - start))
     block = meta["bits"] // 8 * meta["channels"]
     nbytes = count * block
+    if out is not None and (out.dtype != np.uint8 or out.ndim != 1 or out.size < nbytes or not out.flags.c_contiguous):
+        raise ValueError(f"read_raw_range: `out` must be a contiguous uint8 array of at least {nbytes} bytes")
     buf = np.empty(nbytes, dtype=np.uint8) if out is None else out[:nbytes]
     with open(path, "rb", buffering=0) as fh:
         fh.seek(meta["data_offset"] + start * block)
