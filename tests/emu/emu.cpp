@@ -71,8 +71,9 @@ void turn_trig(double frac, double& c, double& s) {
 
 long long g_interior_wgs = 0;   // workgroups of the last emu_band() call that took band_program's interior flavour
 
+// wg_frames (optional): frames per stream of every workgroup, for streams of unequal length (BandArgs::stream_m0)
 template <class C, class LV = upx::LiveAll, bool MERGED = true>
-int run(upx::BandArgs a) {
+int run(upx::BandArgs a, const std::vector<int>* wg_frames = nullptr) {
     g_interior_wgs = 0;
     std::vector<upx::cf> tw((size_t)C::TW_CF);
     upx::fill_tables<C>(tw.data(), turn_trig);
@@ -85,8 +86,17 @@ int run(upx::BandArgs a) {
     a.blocks_per_stream += a.blocks_per_stream & 1;              // the kernel needs an even F (the library rounds up too)
     const long long n_blocks = (long long)a.m_hi - a.m_lo + 1;   // streams start one frame early (frame m_lo - 1)
     if (a.m_hi <= a.m_lo) return 0;
-    const long long n_streams = (n_blocks + a.blocks_per_stream - 1) / a.blocks_per_stream;
-    const long long n_wg = (n_streams + C::G - 1) / C::G;
+    long long n_streams = (n_blocks + a.blocks_per_stream - 1) / a.blocks_per_stream;
+    long long n_wg = (n_streams + C::G - 1) / C::G;
+    std::vector<int> m0;
+    if (wg_frames) {
+        n_wg = (long long)wg_frames->size();
+        n_streams = n_wg * C::G;
+        m0.assign((size_t)n_streams + 1, a.m_lo - 1);
+        for (long long w = 0; w < n_wg; ++w)
+            for (int g = 0; g < C::G; ++g) m0[(size_t)(w * C::G + g) + 1] = m0[(size_t)(w * C::G + g)] + (*wg_frames)[(size_t)w];
+        a.stream_m0 = m0.data();
+    }
     const int tail = (C::P - C::HS) * C::LANES;
     std::vector<float> seam((size_t)n_wg * C::G * 3 * tail, NAN);
     a.seam = seam.data();
@@ -129,6 +139,28 @@ extern "C" int emu_band(int log2n, int k_overlap, int pts, const float* in, long
 #define UPX_WIDE(L, K) if (log2n == L && k_overlap == K && pts == 0) return run<upx::WideCfg<L, K>>(a);
     UPX_WIDE(12, 4) UPX_WIDE(13, 4) UPX_WIDE(12, 2) UPX_WIDE(12, 8) UPX_WIDE(13, 2) UPX_WIDE(13, 8)
 #undef UPX_WIDE
+    return -1;
+}
+
+// Streams of unequal length: workgroup w's streams transform wg_frames[w] frames each (even, >= K; the caller makes the sum
+// cover the signal).  Same arguments as emu_band otherwise (16 points per lane, general flavour).
+extern "C" int emu_band_uneven(int log2n, int k_overlap, const int* wg_frames, int n_wg, const float* in, long long t_in,
+                               float* out_c, float* out_l, float* out_r, long long t_out, const float* w_a,
+                               const float* w_s_scaled, const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi,
+                               int accumulate) {
+    upx::BandArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const upx::cf*>(in);
+    a.out_c = out_c; a.out_l = out_l; a.out_r = out_r;
+    a.w_a = w_a; a.w_s = w_s_scaled; a.gain = gain_half;
+    a.t_in = (int)t_in; a.t_out = (int)t_out;
+    a.j_lo = j_lo; a.j_hi = j_hi; a.m_lo = m_lo; a.m_hi = m_hi;
+    a.blocks_per_stream = 2; a.accumulate = accumulate;
+    a.n_gain = 1; a.gain_stride = (1 << log2n) / 2 + 1;
+    const std::vector<int> frames(wg_frames, wg_frames + n_wg);
+#define UPX_UNEVEN(L, K) if (log2n == L && k_overlap == K) return run<upx::Cfg<L, K, 16>>(a, &frames);
+    UPX_UNEVEN(8, 4) UPX_UNEVEN(10, 4) UPX_UNEVEN(11, 4) UPX_UNEVEN(9, 2)
+#undef UPX_UNEVEN
     return -1;
 }
 

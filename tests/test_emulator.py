@@ -321,3 +321,38 @@ def test_live_slot_flavours(emu, case, pts):
             # (the single-band flavour evaluates the mask through mask_weight: same numbers up to float32 rounding)
             assert float(np.max(np.abs(g - q))) <= 3e-7, "pruned flavour differs from the general one"
             assert rms(g.astype(np.float64) - (r + (0.25 if accumulate else 0.0))) < 1e-7
+
+
+# ---- streams of unequal length (BandArgs::stream_m0: shorter streams for the signal-edge workgroups) ---------------
+@pytest.mark.parametrize("n,k", [(256, 4), (1024, 4), (2048, 4), (512, 2)])
+def test_streams_of_unequal_length(emu, n, k, pts):
+    """Any cut of the frame range into streams (even lengths, equal inside a workgroup) gives the same band output up to the
+    float32 association behind the stream seams; first band and accumulating."""
+    if pts != 16:
+        pytest.skip("one executor suffices")
+    emu.emu_band_uneven.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, fp,
+                                    ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong, fp, fp, fp] + [ctypes.c_int] * 5
+    emu.emu_band_uneven.restype = ctypes.c_int
+    ov = 1.0 - 1.0 / k
+    band = orc.Band(n, ov, 300., 9000., 48000, "raised_cosine", 75., 2000.)
+    hop = band.hop_size
+    g = 64 // (n // 16) if n // 16 < 64 else 1               # streams per workgroup
+    wg_frames = [6, 10, 8, 10, 4]                             # a short first workgroup, a short last one
+    total = (sum(wg_frames) * g - 1) * hop - 37               # frames -1 .. cover the signal; ragged end
+    x = orc.synthetic_stereo(total, n + k)
+    ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+    w_a = np.ascontiguousarray(band.analysis_window)
+    w_s = (band.synthesis_window / np.float32(n)).astype(np.float32)
+    gain = np.ascontiguousarray((0.5 * orc.band_gain(band)).astype(np.float32))
+    xin = np.ascontiguousarray(x, dtype=np.float32)
+    frames = (ctypes.c_int * len(wg_frames))(*wg_frames)
+    j_hi = -(-total // hop)
+    for accumulate in (0, 1):
+        outs = [np.full(total, 0.5 if accumulate else np.nan, np.float32) for _ in range(3)]
+        m_hi = min(j_hi + k - 1, -(-total // hop)) if accumulate else -(-total // hop)
+        rc = emu.emu_band_uneven(int(np.log2(n)), k, frames, len(wg_frames), P(xin), total, P(outs[0]), P(outs[1]),
+                                 P(outs[2]), total, P(w_a), P(w_s), P(gain), 0, j_hi, 0, m_hi, accumulate)
+        assert rc == 0
+        for got, r in zip(outs, ref):
+            assert not np.isnan(got).any()
+            assert rms(got.astype(np.float64) - (r + (0.5 if accumulate else 0.0))) < 1e-7

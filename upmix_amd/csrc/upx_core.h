@@ -605,7 +605,12 @@ struct BandArgs {
     int t_out;             // valid output samples [0, t_out)
     int j_lo, j_hi;        // frames that exist: j in [j_lo, j_hi), frame j starts at j*hop
     int m_lo, m_hi;        // hop-blocks to emit: m in [m_lo, m_hi)
-    int blocks_per_stream; // F
+    int blocks_per_stream; // F (frames of every stream when stream_m0 == nullptr)
+    // Streams of unequal length: stream sid transforms the frames [stream_m0[sid], stream_m0[sid + 1]) (n_streams + 1
+    // entries, even lengths, equal inside a workgroup).  The first and the last workgroups of a launch run the slower
+    // signal-edge flavour: with streams as long as everybody's they end ~12 % late and the launch waits for them, so the
+    // host hands them shorter streams (upx_process_device).  nullptr: stream sid starts at m_lo - 1 + sid F.
+    const int* stream_m0;
     // Adjacent bands that share N, hop and windows are MERGED into one launch: their transforms are
     // the same linear operators, so sum_b OLA(iFFT(Y_b)) = OLA(iFFT(sum_b Y_b)) and only the per-bin
     // gain -> mask step runs per band.  gain[q][k], q < n_gain, lists the non-zero band gains of bin k
@@ -614,9 +619,33 @@ struct BandArgs {
     int gain_stride;
     int accumulate;        // 0: out = band, 1: out += band (band sum in list order)
     float* seam;           // [streams][3][(K-1) hop]: what a stream's last frames add to the NEXT stream's first blocks
+    // Two waves share a SIMD and the hardware arbitrates their instruction issue by priority, then AGE: the workgroups of
+    // the first half of a machine-filling launch (dispatched first, one per SIMD) ran at full speed and ended 20-25 %
+    // before their younger partners, which then finished alone on their SIMDs (measured per workgroup:
+    // scripts/phase_prof/wgtime.hip).  prio_split > 0: workgroups with index >= prio_split raise their priority on every
+    // other frame pair, the others on the pairs in between: both halves advance at the same average rate and end together.
+    // prio_split < 0 (two-wave workgroups, four per CU): -prio_split workgroups per dispatch round, the four rounds of a CU
+    // ran at four speeds (233 / 283 / 283 / 298 us for the same work) and take the top priority in turn, a frame pair each.
+    int prio_split;
+    int prio_young;        // prio_split > 0: frame pairs out of 4 in which the younger half leads (3 balances; 2 = even turns)
 };
 
 constexpr float kEps = 1e-12f;   // center_extraction.py:36
+
+// first frame of stream sid / frames of the streams of workgroup `wg` (G streams per workgroup)
+UPX_HD int stream_first(const BandArgs& a, int sid) {
+    if (a.stream_m0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return ((const UPX_GLOBAL int*)a.stream_m0)[sid];
+#else
+        return a.stream_m0[sid];
+#endif
+    }
+    return a.m_lo - 1 + sid * a.blocks_per_stream;
+}
+UPX_HD int stream_frames(const BandArgs& a, int sid) {
+    return a.stream_m0 ? stream_first(a, sid + 1) - stream_first(a, sid) : a.blocks_per_stream;
+}
 
 // coherence * (1 - |balance|) mask of center_extraction.py:373-384 on one bin.
 // |L conj(R)| is evaluated as |L||R| (identical in exact arithmetic).
@@ -658,6 +687,7 @@ struct ThreadT {
     float g1[P / 2];  // second slot (merged bands)
     float gn[2];      // first two gain slots of the Nyquist bin
     float g0w[P];     // (upx_zoom.h) synthesis window of the pending last phase, fetched ahead
+    int m0;           // first frame of this thread's stream (stream_first)
 };
 
 template <class C>
@@ -936,7 +966,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // same for every partition.  Block m = sum of frames m-K+1..m: the K-1 blocks after m0+F-1 are only
     // partially known here (the "tail") and go to a.seam; upx_stream_seam_add() adds each tail onto the first
     // blocks of the next stream afterwards (same float32 association as the multi-GPU seam).
-    const int F = a.blocks_per_stream;   // even (host guarantees): a stream is a whole number of frame pairs
+    const int F = stream_frames(a, wg_index * C::G);   // even, the same for the streams of a workgroup (host guarantees)
     const int n_iter = F / 2;
     int it = 0;   // the frame-pair counter of the main loop (declared here: the pieces below read it; it outlives the
                   // loop because the host emulator of wide streams runs recorded phases at the next barrier)
@@ -945,9 +975,10 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     const cf* const bigtw = tw + SC::TW_CF;     // wide: W_N^(k1 n2), row k1 at k1 * BT_ROW
 
     // ---- copy the twiddle table into LDS ------------------------------------
-    ex.each([&](int tid, Thread&) {
+    ex.each([&](int tid, Thread& th) {
         const UPX_GLOBAL cf* src = opaque(a.tw);
         for (int i = tid; i < C::TW_CF; i += C::WG) tw[i] = src[i];
+        th.m0 = stream_first(a, wg_index * C::G + tid / LANES);
     });
     if constexpr (WIDE) ex.wg_barrier();
 
@@ -955,8 +986,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // Frame j of a stream covers samples j HOP + lane + s LANES.  Slots s < P-HS were part of the
     // previous frame (L2 hits); the HS "new hop" slots are HBM misses, so they are fetched one frame
     // ahead into th.pre and only consumed here.
-    auto frame_of = [&](int tid, int it, int half, bool& exists) {
-        const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
+    // (a thread's stream start lives in th.m0: set once, below)
+    auto frame_of = [&](int m0, int it, int half, bool& exists) {
         const int j = m0 + 2 * it + half;
         exists = IN || (j >= a.j_lo && j < a.j_hi && j < m0 + F);
         return j;
@@ -966,7 +997,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     // clamps, compares or exec masks (they were a third of the instructions of these phases).
     auto prefetch = [&](int tid, Thread& th, int it, int half) {
         bool exists;
-        const int j = frame_of(tid, it, half, exists);
+        const int j = frame_of(th.m0, it, half, exists);
         const int e = exists ? j * HOP + tid % LANES : 0;
         const UPX_GLOBAL cf* in = opaque(a.in);
         const int last = a.t_in - 1;
@@ -1000,10 +1031,10 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         for (int s = 0; s < P; ++s) hr.wa[s] = gat(w_a, (unsigned)(tid % LANES), s * LANES);
         hr.have_wa = true;
     };
-    auto head_fetch = [&](int tid, int it, int half, HeadRegs& hr) {
+    auto head_fetch = [&](int tid, const Thread& th, int it, int half, HeadRegs& hr) {
         const int lane = tid % LANES;
         bool exists;
-        const int j = frame_of(tid, it, half, exists);
+        const int j = frame_of(th.m0, it, half, exists);
         const int e = exists ? j * HOP + lane : 0;
         const UPX_GLOBAL cf* in = opaque(a.in);
         const int last = a.t_in - 1;   // host guarantees t_in >= 1
@@ -1039,7 +1070,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             for (int s = 0; s < P; ++s) th.x[s] = scale(s < P - HS ? hr.v[s] : th.pre[s < P - HS ? 0 : s - (P - HS)], wa[s]);
         } else {
             bool exists;
-            const int j = frame_of(tid, it, half, exists);
+            const int j = frame_of(th.m0, it, half, exists);
             const int e = exists ? j * HOP + lane : 0;
             const int last = a.t_in - 1;
 #pragma unroll
@@ -1100,8 +1131,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         bool emit;    // this stream emits the hop
         bool fast;    // the whole wave emits a hop that lies inside the planes
     };
-    auto hop_of = [&](int tid, int j) {
-        const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
+    auto hop_of = [&](int m0, int tid, int j) {
         Hop h;
         h.emit = IN || (j >= a.m_lo && j < a.m_hi && j < m0 + F);
         h.e = h.emit ? j * HOP + tid % LANES : 0;
@@ -1127,8 +1157,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     auto no_hook = []() {};
     auto tail_lr = [&](int tid, Thread& th, int it, int half, auto&& before_stores) {
         const int lane = tid % LANES;
-        const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
-        const Hop h = hop_of(tid, m0 + 2 * it + half);
+        const int m0 = th.m0;
+        const Hop h = hop_of(m0, tid, m0 + 2 * it + half);
         UPX_GLOBAL float* out_l = opaque(a.out_l);
         UPX_GLOBAL float* out_r = opaque(a.out_r);
         float old_l[HS], old_r[HS];
@@ -1167,13 +1197,13 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
     };
     auto tail_c = [&](int tid, Thread& th, int it, auto&& before_stores) {
         const int lane = tid % LANES;
-        const int m0 = a.m_lo - 1 + (wg_index * C::G + tid / LANES) * F;
+        const int m0 = th.m0;
         UPX_GLOBAL float* out_c = opaque(a.out_c);
         Hop h[2];
         float old_c[2][HS];
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            h[half] = hop_of(tid, m0 + 2 * it + half);
+            h[half] = hop_of(m0, tid, m0 + 2 * it + half);
             load_old(out_c, h[half], old_c[half]);
         }
         const UPX_GLOBAL float* w_s = opaque(a.w_s);
@@ -1442,6 +1472,29 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         prefetch(tid, th, 0, 0);
     });
 
+    // (see BandArgs::prio_split; a scalar instruction per frame pair, nothing on the host emulator)
+    auto issue_priority = [&](int pair) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (a.prio_split < 0) {
+            // multi-wave workgroups, -prio_split of them per dispatch round (one per CU): the four rounds that share a CU
+            // take the top priority in turn, a frame pair each
+            const int r = (wg_index / (-a.prio_split) + pair) & 3;
+            if (r == 0) __builtin_amdgcn_s_setprio(3);
+            else if (r == 1) __builtin_amdgcn_s_setprio(2);
+            else if (r == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        } else if (a.prio_split > 0) {
+            // of every 4 frame pairs the younger half leads in prio_young, the older half in the others
+            const bool young = wg_index >= a.prio_split;
+            const bool lead = ((pair & 3) < a.prio_young) == young;
+            if (lead) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#else
+        (void)pair;
+#endif
+    };
+
     // One extra trip runs only the centre tail of the last pair.  tail_c is instantiated ONCE
     // (inside this loop) on purpose: two inlined copies may contract multiply-adds differently,
     // and which copy a frame meets would then depend on how the signal is cut into streams.
@@ -1454,16 +1507,17 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         ex.each2(
             [&, it](int tid, Thread& th) {
                 HeadRegs hr;
-                head_fetch(tid, 0, 0, hr);
+                head_fetch(tid, th, 0, 0, hr);
                 head(tid, th, 0, 0, hr);
             },
             head_write);
         for (; it < n_iter; ++it) {
+            issue_priority(it);
             frame_body(0);
             ex.each2(
                 [&, it](int tid, Thread& th) {
                     HeadRegs hr;
-                    head_fetch(tid, it, 1, hr);
+                    head_fetch(tid, th, it, 1, hr);
                     tail_lr(tid, th, it, 0, [&]() { window_fetch(tid, hr); });
                     head(tid, th, it, 1, hr);
                 },
@@ -1480,7 +1534,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
             ex.each2(
                 [&, it](int tid, Thread& th) {
                     HeadRegs hr;
-                    head_fetch(tid, it + 1, 0, hr);
+                    head_fetch(tid, th, it + 1, 0, hr);
                     tail_c(tid, th, it, [&]() { window_fetch(tid, hr); });
                     head(tid, th, it + 1, 0, hr);
                 },
@@ -1488,10 +1542,11 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         }
     } else
     for (; it <= n_iter; ++it) {
+        issue_priority(it);
         ex.each2(
             [&](int tid, Thread& th) {
                 HeadRegs hr;
-                if (it < n_iter) head_fetch(tid, it, 0, hr);
+                if (it < n_iter) head_fetch(tid, th, it, 0, hr);
                 if (it > 0) tail_c(tid, th, it - 1, no_hook);
                 if (it < n_iter) head(tid, th, it, 0, hr);
             },
@@ -1503,7 +1558,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
         ex.each2(
             [&](int tid, Thread& th) {
                 HeadRegs hr;
-                head_fetch(tid, it, 1, hr);
+                head_fetch(tid, th, it, 1, hr);
                 tail_lr(tid, th, it, 0, [&]() { window_fetch(tid, hr); });
                 head(tid, th, it, 1, hr);
             },
@@ -1538,8 +1593,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 // them without using them).
 template <class C>
 UPX_HD bool band_interior(const BandArgs& a, int wg_index) {
-    const long long F = a.blocks_per_stream;
-    const long long first = (long long)a.m_lo - 1 + (long long)wg_index * C::G * F;   // first frame of the first stream
+    const long long F = stream_frames(a, wg_index * C::G);
+    const long long first = stream_first(a, wg_index * C::G);                         // first frame of the first stream
     const long long end = first + C::G * F;                                           // one past the last stream's frames
     const long long lo = a.j_lo > a.m_lo ? a.j_lo : a.m_lo;
     const long long hi = a.j_hi < a.m_hi ? a.j_hi : a.m_hi;
@@ -1561,7 +1616,7 @@ UPX_HD void band_program_auto(Ex& ex, const BandArgs& a, cf* lds_all, int wg_ind
 UPX_HD void stream_seam_add(const BandArgs& a, int n_streams, int tail, int hop, long long gid) {
     const int sid = (int)(gid / tail), i = (int)(gid % tail);
     if (sid >= n_streams - 1) return;                       // the last stream's tail lies beyond the emitted range
-    const long long m = (long long)a.m_lo - 1 + (long long)(sid + 1) * a.blocks_per_stream;
+    const long long m = stream_first(a, sid + 1);
     const long long n = m * hop + i;
     if (m >= a.m_hi || n < 0 || n >= a.t_out) return;
     if (m + i / hop >= a.m_hi) return;                      // blocks past the emitted range stay untouched

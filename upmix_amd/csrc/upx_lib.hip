@@ -201,6 +201,10 @@ struct BandState {
     float* d_gain = nullptr;   // 0.5 * gain
     upx::cf* d_tw = nullptr;   // shared per N (owned by plan->tw)
     int blocks_override = 0;
+    // streams of unequal length (BandArgs::stream_m0): the table of the last geometry, on the host and on the device
+    std::vector<int> h_m0, h_m0_sent;
+    int* d_m0 = nullptr;
+    size_t m0_cap = 0;
     int group_leader = 0;               // index of the band whose launch carries this band
     int group_size = 1;                 // leader: bands merged into its launch; merged members: 0
     int n_gain = 1;                     // gain slots per bin (merged bands overlap at crossovers)
@@ -230,6 +234,8 @@ struct upx_plan {
     double knob_zoom_fill = 2.0;            // UPX_ZOOM_FILL: synthesis streams per resident workgroup slot
     long long knob_zoom_f = 0;              // UPX_ZOOM_F: frames per synthesis stream (0 = automatic)
     long long knob_stream_chunk = 1LL << 22;   // UPX_STREAM_CHUNK: owned samples per chunk of a streamed host call
+    int knob_edge_percent = 88;             // UPX_EDGE_PERCENT: stream length of a fused launch's edge workgroups (100 = uniform)
+    int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
     float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
     size_t seam_floats = 0;
     upx::cf* d_scratch = nullptr;   // z | y | yc of the big path (shared by all big bands)
@@ -400,6 +406,8 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_ZOOM_FILL")) p->knob_zoom_fill = std::atof(e);
     if (const char* e = std::getenv("UPX_ZOOM_F")) p->knob_zoom_f = std::atoll(e);
     if (const char* e = std::getenv("UPX_STREAM_CHUNK")) p->knob_stream_chunk = std::atoll(e);
+    if (const char* e = std::getenv("UPX_EDGE_PERCENT")) p->knob_edge_percent = std::atoi(e);
+    if (const char* e = std::getenv("UPX_PRIO_YOUNG")) p->knob_prio_young = std::atoi(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         p->n_cu = prop.multiProcessorCount;
@@ -635,6 +643,7 @@ void upx_plan_destroy(upx_plan* p) {
         if (s.d_gain) (void)hipFree(s.d_gain);
         if (s.d_tw_n) (void)hipFree(s.d_tw_n);
         if (s.d_ramp) (void)hipFree(s.d_ramp);
+        if (s.d_m0) (void)hipFree(s.d_m0);
         for (auto e : s.ring0) if (e) (void)hipEventDestroy(e);
         for (auto e : s.ring1) if (e) (void)hipEventDestroy(e);
         for (auto e : s.ring_mid) if (e) (void)hipEventDestroy(e);
@@ -867,8 +876,63 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         if (s.blocks_override <= 0 && f < 8) f = 8;
         if (f < s.k) f = s.k;
         f += f & 1;
-        const long long n_streams = (m_hi + 1 + f - 1) / f;
-        const long long n_wg = (n_streams + s.kern->g - 1) / s.kern->g;
+        long long n_streams = (m_hi + 1 + f - 1) / f;
+        long long n_wg = (n_streams + s.kern->g - 1) / s.kern->g;
+        // A launch that fills the machine: the first and the last workgroups run the signal-edge flavour (~12 % slower per
+        // frame; measured per workgroup, scripts/phase_prof/wgtime.hip) and the launch used to wait for them.  They get
+        // streams of edge_percent of the others' length; the others grow by what that frees (stream table, BandArgs).
+        const int G = s.kern->g;
+        const long long slots = target_streams / G;               // workgroups resident at once
+        const long long total = m_hi + 1;                         // frames -1 .. m_hi-1
+        bool uneven = false;
+        if (s.blocks_override <= 0 && p->knob_edge_percent < 100 && p->knob_edge_percent >= 50 && slots >= 8 &&
+            total >= slots * G * 16) {
+            const double share = p->knob_edge_percent / 100.0;
+            long long fu = (long long)std::ceil((double)total / ((double)G * ((double)slots - 2.0 * (1.0 - share))));
+            fu += fu & 1;
+            for (int attempt = 0; attempt < 8 && !uneven; ++attempt, fu += 2) {
+                long long fe = (long long)(share * (double)fu);
+                fe -= fe & 1;
+                if (fe < s.k + (s.k & 1) || fe < 2) break;
+                std::vector<long long> len{fe};
+                long long remaining = total - G * fe;
+                while (remaining > G * fe) {
+                    len.push_back(fu);
+                    remaining -= G * fu;
+                }
+                if (remaining > 0) {
+                    long long last = (remaining + G - 1) / G;
+                    last += last & 1;
+                    if (last < s.k + (s.k & 1)) last = s.k + (s.k & 1);
+                    len.push_back(last);
+                }
+                if ((long long)len.size() > slots) continue;        // one workgroup too many: longer streams
+                s.h_m0.assign(len.size() * G + 1, 0);
+                s.h_m0[0] = -1;
+                for (size_t w = 0; w < len.size(); ++w)
+                    for (int g = 0; g < G; ++g) s.h_m0[w * G + g + 1] = s.h_m0[w * G + g] + (int)len[w];
+                n_wg = (long long)len.size();
+                n_streams = n_wg * G;
+                f = fu;
+                uneven = true;
+            }
+        }
+        if (uneven) {
+            // the table goes to the device on the plan's stream, ordered with the launch (the host copy stays in the plan)
+            if (s.h_m0.size() > s.m0_cap) {
+                HIP_TRY(hipStreamSynchronize(p->stream));
+                if (s.d_m0) HIP_TRY(hipFree(s.d_m0));
+                s.d_m0 = nullptr;
+                s.m0_cap = 0;
+                HIP_TRY(hipMalloc(&s.d_m0, s.h_m0.size() * sizeof(int)));
+                s.m0_cap = s.h_m0.size();
+            }
+            if (s.h_m0 != s.h_m0_sent) {   // (a repeated call on the same geometry - every step of a benchmark - sends nothing)
+                HIP_TRY(hipMemcpyAsync(s.d_m0, s.h_m0.data(), s.h_m0.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
+                HIP_TRY(hipStreamSynchronize(p->stream));   // the host copy may change on the next call
+                s.h_m0_sent = s.h_m0;
+            }
+        }
         const long long tail = (long long)(s.k - 1) * s.hop;
         const size_t seam_need = (size_t)n_wg * s.kern->g * 3 * tail;
         if (seam_need > p->seam_floats) {
@@ -886,8 +950,19 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         a.t_in = (int)t_in; a.t_out = (int)t_out;
         a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
         a.blocks_per_stream = (int)f;
+        a.stream_m0 = uneven ? s.d_m0 : nullptr;
         a.accumulate = b == 0 ? 0 : 1;
         a.seam = p->d_seam;
+        // one-wave workgroups that fill the machine: the first `SIMDs` of them are the older wave of their SIMD
+        // (BandArgs::prio_split)
+        // ... and two-wave workgroups (N = 2048: four per CU) run at four speeds by dispatch round; the rounds take the top
+        // priority in turn (prio_split < 0: workgroups per round)
+        a.prio_split = 0;
+        if (p->knob_prio_young > 0 && p->knob_prio_young < 4) {
+            if (s.kern->wg == 64 && n_wg > 4LL * p->n_cu) a.prio_split = 4 * p->n_cu;
+            else if (s.kern->wg == 128 && n_wg > 2LL * p->n_cu) a.prio_split = -p->n_cu;
+        }
+        a.prio_young = p->knob_prio_young;
         s.last_wg = (int)n_wg;
         s.last_f = (int)f;
         if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
