@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--seconds", type=float, default=None, help="audio per GPU / per track (default: the workload's)")
+    ap.add_argument("--preheat-ms", type=float, default=200.0,
+                    help="untimed steps for this long before the W warm-up steps: the card leaves its idle power state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive side measurements")
     args = ap.parse_args()
@@ -352,6 +354,22 @@ def main():
         plan.sync()
         group.barrier()
 
+    # An idle card needs ~20 steps (30 ms of work) to reach its running clocks (scripts/clock_ramp_check.py: 1.85,
+    # 1.63, 1.54, 1.51 ms for the first groups of five steps, 1.49 from the sixth on; the same again after 2 s of
+    # idling).  The metric is sustained throughput, so the ramp is run down before the W warm-up steps, untimed, and
+    # reported in the line (`preheat`); --preheat-ms 0 switches it off.
+    preheat_steps = 0
+    if args.preheat_ms > 0:
+        t_pre = time.perf_counter()
+        for _ in range(5):
+            step()
+        plan.sync()
+        # every rank runs the same number of steps (a step of the sharded path ends in a collective)
+        per_step_ms = group.allreduce_max([(time.perf_counter() - t_pre) * 1e3 / 5])[0]
+        preheat_steps = max(5, min(2000, int(np.ceil(args.preheat_ms / max(per_step_ms, 1e-3)))))
+        for _ in range(preheat_steps - 5):
+            step()
+        plan.sync()
     for _ in range(args.warmup):
         step()
     plan.enable_timing(True)
@@ -434,6 +452,9 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "preheat": {"untimed_steps": preheat_steps, "ms": args.preheat_ms,
+                        "why": "an idle card reaches its running clocks after ~20 steps; run before the warm-up steps, "
+                               "never inside the timed region (scripts/clock_ramp_check.py, DESIGN.md 5)"},
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",

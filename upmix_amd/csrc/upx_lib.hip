@@ -850,6 +850,12 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                 if (per_xcd > (pairs + 7) / 8) per_xcd = (pairs + 7) / 8;
                 if (per_xcd < 1) per_xcd = 1;
                 a.pairs_per_wg = (int)per_xcd;
+                {   // the analysis fills every resident slot once: its workgroups take the top priority in turn (ZoomArgs)
+                    const int res = zoom_resident(s, true);
+                    a.prio_split = (p->knob_prio_young > 0 && res >= 2 && res <= 4 && 8 * per_xcd >= (long long)p->n_cu * res)
+                                       ? p->n_cu : 0;
+                    a.prio_rounds = res;
+                }
                 if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
                 s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
                 if (split) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));

@@ -75,6 +75,10 @@ struct ZoomArgs {
     int pair0, pair_end;   // analysis launch: pairs [pair0, pair_end)
     int pairs_per_wg;      // analysis launch: workgroups per XCD (grid = 8 x this; see zoom_analysis_program)
     int stream0;           // synthesis launch: first stream
+    // analysis launch (every resident slot once, a static share of the pairs each): the workgroups that share a CU were
+    // dispatched in `prio_rounds` rounds of `prio_split` and the hardware favours the older ones (BandArgs::prio_split);
+    // they take the top priority in turn, a pair each.  0: off.
+    int prio_split, prio_rounds;
 };
 
 template <int LOG2P_, int RG_, int K_>
@@ -306,7 +310,17 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
     if (Z::PREFETCH_A && cur.q < q_stop) ex.each([&, cur](int tid, Thread& th) { request(tid, th, cur); });
 
     // frames are visited pair by pair; a pair whose frames do not exist still writes its (zero) centre spectrum
-    for (int q = a.pair0 + xcd * per_xcd + l; q < q_stop; q += n_l) {
+    int turn = 0;
+    for (int q = a.pair0 + xcd * per_xcd + l; q < q_stop; q += n_l, ++turn) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (a.prio_split > 0) {
+            const int r = (wg_index / a.prio_split + turn) % a.prio_rounds;
+            if (r == 0) __builtin_amdgcn_s_setprio(3);
+            else if (r == 1) __builtin_amdgcn_s_setprio(2);
+            else if (r == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         for (int half = 0; half < 2; ++half) {
             const int j = 2 * q - 1 + half;
             const bool ex_j = exists(j);
