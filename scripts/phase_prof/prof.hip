@@ -56,21 +56,22 @@ struct ProfExec {
     }
 };
 
-template <class C>
+template <class C, class LV>
 __global__ __launch_bounds__(C::WG, 2) void prof_kernel(upx::BandArgs a, unsigned long long* buf, int cap, int wave) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ProfExec<C::WAVE_SYNC || C::WIDE, C::P> ex;
     ex.buf = buf; ex.cap = cap;
     // a workgroup in the middle of the launch: it runs band_program's interior flavour (rotated loop)
     ex.rec = blockIdx.x == gridDim.x / 2 && (int)(threadIdx.x / 64) == wave;
-    upx::band_program_auto<C>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    // single band (MERGED = false) with the live-slot flavour the plan would pick, like the product launch
+    upx::band_program_auto<C, decltype(ex), false, LV>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
 
 static void turn_trig(double frac, double& c, double& s) { c = std::cos(2 * M_PI * frac); s = std::sin(2 * M_PI * frac); }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <class C>
+template <class C, class LV = upx::LiveAll>
 int run(int F, int n_wg, int wave, int n_gain) {
     const int N = C::N, HOP = C::HOP;
     const long long n_streams = (long long)n_wg * C::G;
@@ -96,11 +97,12 @@ int run(int F, int n_wg, int wave, int n_gain) {
     a.t_in = (int)T; a.t_out = (int)T; a.j_lo = 0; a.j_hi = (int)blocks; a.m_lo = 0; a.m_hi = (int)blocks;
     a.blocks_per_stream = F; a.n_gain = n_gain; a.gain_stride = N / 2 + 1; a.accumulate = 0; a.seam = d_seam;
     const int lds = C::LDS_CF * 8;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&prof_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const void* kfn = reinterpret_cast<const void*>(&prof_kernel<C, LV>);
+    CK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL(prof_kernel<C>, dim3(n_wg), dim3(C::WG), lds, 0, a, d_buf, cap, wave);
+        hipLaunchKernelGGL((prof_kernel<C, LV>), dim3(n_wg), dim3(C::WG), lds, 0, a, d_buf, cap, wave);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("N=%d wide=%d F=%d wgs=%d lds=%d: %.3f ms  (%.1f Msamples/s)\n", N, (int)C::WIDE, F, n_wg, lds, ms, T / ms / 1e3);
@@ -128,7 +130,7 @@ int main(int argc, char** argv) {
     if (log2n == 13) return run<upx::Cfg<13, 4, 16>>(F, wgs, wave, ng);
     if (log2n == 12 && wide) return run<upx::WideCfg<12, 4>>(F, wgs, wave, ng);
     if (log2n == 12) return run<upx::Cfg<12, 4, 16>>(F, wgs, wave, ng);
-    if (log2n == 10) return run<upx::Cfg<10, 4, 16>>(F, wgs, wave, ng);
+    if (log2n == 10) return run<upx::Cfg<10, 4, 16>, upx::Live<0, 4>>(F, wgs, wave, ng);
     if (log2n == 8) return run<upx::Cfg<8, 4, 16>>(F, wgs, wave, ng);
     return 1;
 }

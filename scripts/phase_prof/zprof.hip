@@ -64,8 +64,11 @@ __global__ __launch_bounds__(Z::WG, Z::WPE_S) void zsyn(upx::ZoomArgs a, unsigne
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ProfExec ex;
     ex.buf = buf; ex.cap = cap;
-    ex.rec = blockIdx.x == 0 && blockIdx.y == 0 && (int)blockIdx.z == rec_role && (int)(threadIdx.x / 64) == wave;
+    // a stream in the middle of the signal (interior flavour); ZPROF_RAW: stamps at entry and exit as well
+    ex.rec = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && (int)blockIdx.z == rec_role && (int)(threadIdx.x / 64) == wave;
+    if (a.prio_rounds == -1) ex.stamp();
     upx::zoom_synthesis_program<Z>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+    if (a.prio_rounds == -1) { __builtin_amdgcn_s_waitcnt(0); ex.stamp(); }
 }
 
 static void turn_trig(double frac, double& c, double& s) { c = std::cos(2 * M_PI * frac); s = std::sin(2 * M_PI * frac); }
@@ -90,7 +93,7 @@ int run(int log2n, int kernel, int period, int F, int frames) {
     CK(hipMalloc(&d_wa, N * 4)); CK(hipMalloc(&d_ws, N * 4)); CK(hipMalloc(&d_gain, gain.size() * 4));
     CK(hipMalloc(&d_tw, tw.size() * 8)); CK(hipMalloc(&d_ramp, ramp.size() * 8));
     CK(hipMalloc(&d_y, (size_t)frames * P * 12));
-    CK(hipMalloc(&d_seam, n_streams * 3 * (Z::K - 1) * hop * 4)); CK(hipMalloc(&d_buf, cap * 8));
+    CK(hipMalloc(&d_seam, n_streams * 3 * (Z::K - 1) * hop * 4));   // [streams][2][tail] Ls/Rs, then [streams][tail] centre CK(hipMalloc(&d_buf, cap * 8));
     CK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_wa, wa.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ws, ws.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_gain, gain.data(), gain.size() * 4, hipMemcpyHostToDevice));
@@ -98,10 +101,11 @@ int run(int log2n, int kernel, int period, int F, int frames) {
     CK(hipMemset(d_buf, 0, cap * 8));
     upx::ZoomArgs a{};
     a.in = (const upx::cf*)d_in; a.out_c = d_c; a.out_l = d_l; a.out_r = d_r; a.w_a = d_wa; a.w_s = d_ws; a.gain = d_gain;
-    a.tw = d_tw; a.ramp = d_ramp; a.y = d_y; a.yc = d_y + (size_t)frames * P; a.seam = d_seam;
+    a.tw = d_tw; a.ramp = d_ramp; a.y = d_y; a.yc = d_y + (size_t)frames * P; a.seam = d_seam; a.seam_c = d_seam + n_streams * 2 * (Z::K - 1) * hop;
     a.n = N; a.d = D; a.hop = hop; a.t_in = (int)T; a.t_out = (int)T; a.j_lo = 0; a.j_hi = frames; a.m_lo = 0; a.m_hi = frames - 1;
     a.blocks_per_stream = F; a.n_gain = 1; a.gain_stride = N / 2 + 1; a.accumulate = 1; a.f0 = -1;
     a.pair0 = 0; a.pair_end = frames / 2; a.stream0 = 0;
+    if (getenv("ZPROF_RAW")) a.prio_rounds = -1;   // (prio_split = 0: unused by the kernels; here: stamp entry and exit)
     const int lds = Z::LDS_S_CF * 8, lds_a = Z::LDS_A_CF * 8;
     int resident = (Z::WPE_A * 256) / Z::WG; if (resident > (160 * 1024) / lds_a) resident = (160 * 1024) / lds_a;
     const long long slots = 256LL * resident;
@@ -124,6 +128,11 @@ int run(int log2n, int kernel, int period, int F, int frames) {
     CK(hipMemcpy(buf.data(), d_buf, cap * 8, hipMemcpyDeviceToHost));
     int n = 0; while (n < cap && buf[n]) ++n;
     printf("events %d\n", n);
+    if (getenv("ZPROF_RAW")) {
+        printf("raw stamp deltas (cycles), entry first:");
+        for (int k = 1; k < n; ++k) printf("%s%llu", (k - 1) % 16 == 0 ? "\n  " : " ", buf[k] - buf[k - 1]);
+        printf("\n  total %llu cycles\n", buf[n - 1] - buf[0]);
+    }
     if (n > 3 * period) {
         std::vector<double> acc(period, 0.0); int cnt = 0;
         // skip the first period and the tail; the kernel's prologue stamps shift the phase: print from stamp `off`

@@ -314,8 +314,11 @@ extern "C" int emu_pipeline(long long n_items, long long fail_submit, long long 
 
 // ---- band-limited ("zoom") path: analysis kernel, synthesis kernel, stream seams (upx_zoom.h) ------------
 namespace {
+// streams: uniform (blocks_per_stream for both roles, or F / c_split for the centre), or - tab_lr != nullptr - the two
+// tables of first frames (n + 1 entries each; ZoomArgs::stream_m0 / stream_m0_c)
 template <class Z>
-int run_zoom(upx::ZoomArgs a, int pairs_per_wg) {
+int run_zoom(upx::ZoomArgs a, int pairs_per_wg, int c_split, const int* tab_lr = nullptr, int n_lr = 0,
+             const int* tab_c = nullptr, int n_c = 0) {
     using Sub = typename Z::Sub;
     std::vector<upx::cf> tw((size_t)Z::TW_CF), ramp(upx::zoom_ramp_count(a.n, Z::P));
     upx::fill_twiddles<Sub>(tw.data(), turn_trig);
@@ -325,17 +328,37 @@ int run_zoom(upx::ZoomArgs a, int pairs_per_wg) {
     a.d = a.n / Z::P;
     a.blocks_per_stream += a.blocks_per_stream & 1;
     if (a.m_hi <= a.m_lo) return 0;
-    const int F = a.blocks_per_stream;
-    const long long n_streams = ((long long)a.m_hi - a.m_lo + 1 + F - 1) / F;
     const int groups = a.d / Z::RG;
+    const size_t tail = (size_t)(Z::K - 1) * a.hop;
+    long long n_streams, n_streams_c;
+    int n_frames;
+    if (tab_lr) {
+        if (tab_lr[0] != a.m_lo - 1 || tab_c[0] != tab_lr[0] || tab_c[n_c] != tab_lr[n_lr]) return -3;
+        for (int i = 0; i < n_lr; ++i)
+            if ((tab_lr[i + 1] - tab_lr[i]) % 2 != 0 || tab_lr[i + 1] - tab_lr[i] < Z::K) return -3;
+        for (int i = 0; i < n_c; ++i)
+            if ((tab_c[i + 1] - tab_c[i]) % 2 != 0 || tab_c[i + 1] - tab_c[i] < Z::K) return -3;
+        if (tab_lr[n_lr] < a.m_hi) return -3;   // the streams cover frames m_lo - 1 .. m_hi - 1
+        n_streams = n_lr; n_streams_c = n_c;
+        n_frames = tab_lr[n_lr] - tab_lr[0];
+        a.stream_m0 = tab_lr; a.stream_m0_c = tab_c;
+    } else {
+        const int F = a.blocks_per_stream;
+        n_streams = ((long long)a.m_hi - a.m_lo + 1 + F - 1) / F;
+        n_frames = (int)(n_streams * F);
+        // centre streams of their own length (ZoomArgs::blocks_per_stream_c): c_split per Ls/Rs stream
+        if (c_split > 1 && (F % (2 * c_split) != 0 || F / c_split < Z::K)) return -2;
+        const int Fc = F / c_split;
+        n_streams_c = ((long long)a.m_hi - a.m_lo + 1 + Fc - 1) / Fc;
+        if (c_split > 1) a.blocks_per_stream_c = Fc;
+    }
     a.f0 = a.m_lo - 1;
-    const int n_frames = (int)(n_streams * F);
     std::vector<upx::cf> y((size_t)n_frames * Z::P, upx::mk(NAN, NAN)), yc((size_t)(n_frames / 2) * Z::P, upx::mk(NAN, NAN));
     a.y = y.data();
     a.yc = yc.data();
-    const size_t tail = (size_t)(Z::K - 1) * a.hop;
-    std::vector<float> seam((size_t)n_streams * 3 * tail, NAN);
+    std::vector<float> seam((size_t)n_streams * 2 * tail, NAN), seam_c((size_t)n_streams_c * tail, NAN);
     a.seam = seam.data();
+    a.seam_c = seam_c.data();
     std::vector<upx::cf> lds((size_t)Z::LDS_CF);
     // analysis: pairs q0 .. q0 + n_frames/2 - 1
     a.pair0 = a.m_lo / 2;
@@ -347,28 +370,27 @@ int run_zoom(upx::ZoomArgs a, int pairs_per_wg) {
         for (auto& v : lds) v = upx::mk(NAN, NAN);
         upx::zoom_analysis_program<Z>(ex, a, lds.data(), wg);
     }
-    a.stream0 = 0;
+    a.stream0 = 0; a.stream0_c = 0;
+    a.ns_lr = (int)n_streams; a.ns_c = (int)n_streams_c;
     for (int role = 0; role < 2; ++role)
-        for (long long sid = 0; sid < n_streams; ++sid)
+        for (long long sid = 0; sid < (role ? n_streams_c : n_streams); ++sid)
             for (int grp = 0; grp < groups; ++grp) {
                 WaveExec<16> ex;
                 ex.st.resize(Z::WG);
                 for (auto& v : lds) v = upx::mk(NAN, NAN);
                 upx::zoom_synthesis_program<Z>(ex, a, lds.data(), (int)sid, grp, role);
             }
-    upx::BandArgs b;
-    std::memset(&b, 0, sizeof b);
-    b.out_c = a.out_c; b.out_l = a.out_l; b.out_r = a.out_r;
-    b.t_out = a.t_out; b.m_lo = a.m_lo; b.m_hi = a.m_hi; b.blocks_per_stream = F; b.seam = a.seam;
-    for (long long g = 0; g < n_streams * (long long)tail; ++g) upx::stream_seam_add(b, (int)n_streams, (int)tail, a.hop, g);
+    for (long long g = 0; g < (n_streams + n_streams_c) * (long long)tail; ++g)
+        upx::zoom_seam_add(a, (int)n_streams, (int)n_streams_c, (int)tail, g);
     return 0;
 }
 }   // namespace
 
-extern "C" int emu_zoom_band(int log2n, int k_overlap, int log2p, const float* in, long long t_in, float* out_c,
-                             float* out_l, float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
-                             const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int blocks_per_stream,
-                             int accumulate, int n_gain, int pairs_per_wg) {
+extern "C" int emu_zoom_band_streams(int log2n, int k_overlap, int log2p, const float* in, long long t_in, float* out_c,
+                                     float* out_l, float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
+                                     const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int blocks_per_stream,
+                                     int accumulate, int n_gain, int pairs_per_wg, int c_split, const int* tab_lr, int n_lr,
+                                     const int* tab_c, int n_c) {
     upx::ZoomArgs a;
     std::memset(&a, 0, sizeof a);
     a.in = reinterpret_cast<const upx::cf*>(in);
@@ -381,11 +403,19 @@ extern "C" int emu_zoom_band(int log2n, int k_overlap, int log2p, const float* i
     a.n_gain = n_gain; a.gain_stride = a.n / 2 + 1;
     const int d = a.n >> log2p;
     const int rg = d >= 16 ? 16 : d;
-#define UPX_ZOOM(LP, RG, K) if (log2p == LP && rg == RG && k_overlap == K) return run_zoom<upx::ZoomCfg<LP, RG, K>>(a, pairs_per_wg);
+#define UPX_ZOOM(LP, RG, K) if (log2p == LP && rg == RG && k_overlap == K) return run_zoom<upx::ZoomCfg<LP, RG, K>>(a, pairs_per_wg, c_split, tab_lr, n_lr, tab_c, n_c);
 #define UPX_ZOOM_K(LP, RG) UPX_ZOOM(LP, RG, 2) UPX_ZOOM(LP, RG, 4) UPX_ZOOM(LP, RG, 8)
     UPX_ZOOM_K(8, 4) UPX_ZOOM_K(8, 8) UPX_ZOOM_K(8, 16) UPX_ZOOM_K(9, 4) UPX_ZOOM_K(9, 8) UPX_ZOOM_K(9, 16)
     UPX_ZOOM_K(10, 4) UPX_ZOOM_K(10, 8) UPX_ZOOM_K(10, 16)
 #undef UPX_ZOOM_K
 #undef UPX_ZOOM
     return -1;
+}
+
+extern "C" int emu_zoom_band(int log2n, int k_overlap, int log2p, const float* in, long long t_in, float* out_c,
+                             float* out_l, float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,
+                             const float* gain_half, int j_lo, int j_hi, int m_lo, int m_hi, int blocks_per_stream,
+                             int accumulate, int n_gain, int pairs_per_wg) {
+    return emu_zoom_band_streams(log2n, k_overlap, log2p, in, t_in, out_c, out_l, out_r, t_out, w_a, w_s_scaled, gain_half, j_lo,
+                                 j_hi, m_lo, m_hi, blocks_per_stream, accumulate, n_gain, pairs_per_wg, 1, nullptr, 0, nullptr, 0);
 }

@@ -20,6 +20,9 @@ def emu():
     lib = ctypes.CDLL(ge.build_emulator())
     lib.emu_zoom_band.argtypes = [ctypes.c_int] * 3 + [fp, ctypes.c_longlong, fp, fp, fp, ctypes.c_longlong, fp, fp, fp] + [ctypes.c_int] * 8
     lib.emu_zoom_band.restype = ctypes.c_int
+    ip = ctypes.POINTER(ctypes.c_int)
+    lib.emu_zoom_band_streams.argtypes = lib.emu_zoom_band.argtypes + [ctypes.c_int, ip, ctypes.c_int, ip, ctypes.c_int]
+    lib.emu_zoom_band_streams.restype = ctypes.c_int
     return lib
 
 
@@ -37,7 +40,8 @@ def zoom_p(gain_rows):
 
 
 def run_zoom(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=None, t_out=None, gain_table=None,
-             log2p=None, pairs_per_wg=3):
+             log2p=None, pairs_per_wg=3, c_split=1, tables=None):
+    """tables = (first frames of the Ls/Rs streams, of the centre streams), n + 1 entries each (ZoomArgs::stream_m0)"""
     n, hop = band.block_size, band.hop_size
     k = n // hop
     t_in = len(x)
@@ -54,9 +58,15 @@ def run_zoom(lib, band, x, blocks_per_stream, outs=None, accumulate=0, own_len=N
     if outs is None:
         outs = [np.full(t_out, np.nan, np.float32) for _ in range(3)]
     xin = np.ascontiguousarray(x, dtype=np.float32)
-    rc = lib.emu_zoom_band(int(np.log2(n)), k, int(np.log2(p)), P(xin), t_in, P(outs[0]), P(outs[1]), P(outs[2]), t_out,
-                           P(w_a), P(w_s), P(gain), 0, j_hi, 0, m_hi, blocks_per_stream, accumulate, gain.shape[0],
-                           pairs_per_wg)
+    ip = ctypes.POINTER(ctypes.c_int)
+    if tables is None:
+        tab = (None, 0, None, 0)
+    else:
+        t_lr, t_c = (np.ascontiguousarray(t, dtype=np.int32) for t in tables)
+        tab = (t_lr.ctypes.data_as(ip), len(t_lr) - 1, t_c.ctypes.data_as(ip), len(t_c) - 1)
+    rc = lib.emu_zoom_band_streams(int(np.log2(n)), k, int(np.log2(p)), P(xin), t_in, P(outs[0]), P(outs[1]), P(outs[2]),
+                                   t_out, P(w_a), P(w_s), P(gain), 0, j_hi, 0, m_hi, blocks_per_stream, accumulate,
+                                   gain.shape[0], pairs_per_wg, c_split, *tab)
     assert rc == 0, rc
     return outs
 
@@ -111,6 +121,80 @@ def test_stream_partition_changes_only_seam_rounding(emu):
             for m in range(-1 + f, 80, f):
                 seam_blocks.update(range(m, m + 3))
             assert all((int(i) // 1024) in seam_blocks for i in differ), f
+
+
+def test_centre_streams_of_their_own_length(emu):
+    """ZoomArgs::blocks_per_stream_c: the centre plane cut into 2 or 4 streams per Ls/Rs stream.  Ls / Rs do not change at
+    all; the centre differs from the unsplit run only on the K-1 blocks after the additional seams, by rounding."""
+    band = orc.Band(4096, 0.75, 480., 1920., 48000, "raised_cosine", 120., 480.)
+    x = orc.synthetic_stereo(70000, 6)
+    ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+    for f, split in ((8, 2), (16, 2), (16, 4), (24, 2)):
+        base = run_zoom(emu, band, x, f)
+        got = run_zoom(emu, band, x, f, c_split=split)
+        assert np.array_equal(base[1], got[1]) and np.array_equal(base[2], got[2])
+        assert not np.isnan(got[0]).any()
+        assert rms(got[0].astype(np.float64) - ref[0]) < 1e-7
+        fc = f // split
+        differ = np.nonzero(base[0] != got[0])[0]
+        seam_blocks = set()
+        for m in range(-1 + fc, 80, fc):
+            seam_blocks.update(range(m, m + 3))
+        assert all((int(i) // 1024) in seam_blocks for i in differ), (f, split)
+    # accumulate onto existing planes, merged gain list, two residue groups (N = 8192, P = 256)
+    band = orc.Band(8192, 0.75, 120., 480., 48000, "raised_cosine", 30., 120.)
+    x = orc.synthetic_stereo(90000, 7)
+    ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+    outs = [np.full(len(x), 0.25, np.float32) for _ in range(3)]
+    got = run_zoom(emu, band, x, 8, outs=outs, accumulate=1, c_split=2)
+    for g, r in zip(got, ref):
+        assert rms(g.astype(np.float64) - 0.25 - r) < 1e-7
+    # a length the split does not divide is refused by the emulator's driver
+    with pytest.raises(AssertionError):
+        run_zoom(emu, band, x, 6, c_split=2)
+
+
+def deal(first_pair, n_pairs, n):
+    """Stream starts the library deals: n streams over n_pairs frame pairs, lengths within one pair of each other."""
+    return [-1 + 2 * (first_pair + n_pairs * i // n) for i in range(n)] + [-1 + 2 * (first_pair + n_pairs)]
+
+
+def test_stream_tables_one_workgroup_per_slot(emu):
+    """ZoomArgs::stream_m0 / stream_m0_c: the geometry upx_process_device uses - streams of unequal length, the centre
+    streams about twice as long as the Ls/Rs ones; equals the oracle, and equals the uniform cut away from the seams."""
+    band = orc.Band(4096, 0.75, 480., 1920., 48000, "raised_cosine", 120., 480.)
+    x = orc.synthetic_stereo(100000, 9)
+    ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+    frames = -(-len(x) // 1024) + 1
+    pairs = (frames + 1) // 2
+    for n_lr, n_c in ((7, 4), (9, 3), (1, 1), (5, 5)):
+        tabs = (deal(0, pairs, n_lr), deal(0, pairs, n_c))
+        got = run_zoom(emu, band, x, 1000, tables=tabs)
+        for g, r in zip(got, ref):
+            assert not np.isnan(g).any()
+            assert rms(g.astype(np.float64) - r) < 1e-7, (n_lr, n_c)
+    base = run_zoom(emu, band, x, 1000)
+    tabs = (deal(0, pairs, 6), deal(0, pairs, 3))
+    got = run_zoom(emu, band, x, 1000, tables=tabs)
+    for plane, tab in ((0, tabs[1]), (1, tabs[0]), (2, tabs[0])):
+        differ = np.nonzero(base[plane] != got[plane])[0]
+        seam_blocks = set()
+        for m in tab[1:-1]:
+            seam_blocks.update(range(m, m + 3))
+        assert len(differ) > 0 and all((int(i) // 1024) in seam_blocks for i in differ), plane
+    # merged gain list, two residue groups, accumulate (N = 8192, P = 256)
+    band = orc.Band(8192, 0.75, 120., 480., 48000, "raised_cosine", 30., 120.)
+    x = orc.synthetic_stereo(120000, 7)
+    ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), band)
+    frames = -(-len(x) // 2048) + 1
+    pairs = (frames + 1) // 2
+    outs = [np.full(len(x), 0.25, np.float32) for _ in range(3)]
+    got = run_zoom(emu, band, x, 1000, outs=outs, accumulate=1, tables=(deal(0, pairs, 5), deal(0, pairs, 2)))
+    for g, r in zip(got, ref):
+        assert rms(g.astype(np.float64) - 0.25 - r) < 1e-7
+    # a table that does not cover the frames, or holds an odd length, is refused by the emulator's driver
+    with pytest.raises(AssertionError):
+        run_zoom(emu, band, x, 1000, tables=([-1, 8, 2 * pairs - 1], [-1, 2 * pairs - 1]))
 
 
 def test_band_accumulation_and_merged_gain_list(emu):

@@ -130,17 +130,25 @@ __global__ __launch_bounds__(Z::WG, Z::WPE_A) void upx_zoom_analysis_kernel(upx:
     DevExec<true, 16> ex;
     upx::zoom_analysis_program<Z>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
 }
-// grid = (streams, residue groups, role): role 0 = Ls/Rs streams, 1 = centre streams
+// grid = (ns_lr + ns_c) x residue groups workgroups: the Ls/Rs streams first (stream fastest, then residue group), the
+// centre streams - half the work each, or less (ZoomArgs::blocks_per_stream_c) - behind them: longest first
 template <class Z>
-__global__ __launch_bounds__(Z::WG, Z::WPE_S) void upx_zoom_synthesis_kernel(upx::ZoomArgs a) {
+__global__ __launch_bounds__(Z::WG, Z::WPE_S) void upx_zoom_synthesis_kernel(upx::ZoomArgs a, int n_groups) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<true, 16> ex;
-    upx::zoom_synthesis_program<Z>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+    int b = (int)blockIdx.x;
+    const int n0 = a.ns_lr * n_groups;
+    if (b < n0) {
+        upx::zoom_synthesis_program<Z>(ex, a, reinterpret_cast<upx::cf*>(smem), b % a.ns_lr, b / a.ns_lr, 0);
+    } else {
+        b -= n0;
+        upx::zoom_synthesis_program<Z>(ex, a, reinterpret_cast<upx::cf*>(smem), b % a.ns_c, b / a.ns_c, 1);
+    }
 }
 
 struct ZoomEntry {
     void (*analysis)(const upx::ZoomArgs&, int n_wg, hipStream_t);
-    void (*synthesis)(const upx::ZoomArgs&, int n_streams, int n_groups, hipStream_t);
+    void (*synthesis)(const upx::ZoomArgs&, int n_groups, hipStream_t);   // streams: ZoomArgs::ns_lr, ns_c
     int (*prepare)();
     void (*fill_tw)(upx::cf*);
     int p, rg, k, wg, lds_bytes, tw_cf, wpe;   // lds_bytes / wpe: synthesis
@@ -231,8 +239,8 @@ struct ZoomImpl {
     static void analysis(const upx::ZoomArgs& a, int n_wg, hipStream_t st) {
         hipLaunchKernelGGL((upx_zoom_analysis_kernel<Z>), dim3(n_wg), dim3(Z::WG), kLdsA, st, a);
     }
-    static void synthesis(const upx::ZoomArgs& a, int n_streams, int n_groups, hipStream_t st) {
-        hipLaunchKernelGGL((upx_zoom_synthesis_kernel<Z>), dim3(n_streams, n_groups, 2), dim3(Z::WG), kLdsS, st, a);
+    static void synthesis(const upx::ZoomArgs& a, int n_groups, hipStream_t st) {
+        hipLaunchKernelGGL((upx_zoom_synthesis_kernel<Z>), dim3((a.ns_lr + a.ns_c) * n_groups), dim3(Z::WG), kLdsS, st, a, n_groups);
     }
     static int prepare() {
         int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&upx_zoom_analysis_kernel<Z>),

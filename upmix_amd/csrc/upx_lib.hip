@@ -57,6 +57,12 @@ __global__ void upx_stream_seam_add_kernel(upx::BandArgs a, int n_streams, int t
         upx::stream_seam_add(a, n_streams, tail, hop, g);
 }
 
+__global__ void upx_zoom_seam_add_kernel(upx::ZoomArgs a, int n_lr, int n_c, int tail) {
+    const long long total = ((long long)n_lr + n_c) * tail;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x)
+        upx::zoom_seam_add(a, n_lr, n_c, tail, g);
+}
+
 // max |x| as a bit pattern: non-negative floats order like their bit patterns, and a NaN (sign cleared) lies above
 // every number, so a NaN anywhere gives NaN - what np.max(np.abs(.)) gives main.py:53, :85-88
 __global__ void upx_absmax_kernel(const float* x, long long n, unsigned int* result) {
@@ -235,6 +241,9 @@ struct upx_plan {
     long long knob_zoom_f = 0;              // UPX_ZOOM_F: frames per synthesis stream (0 = automatic)
     long long knob_stream_chunk = 1LL << 22;   // UPX_STREAM_CHUNK: owned samples per chunk of a streamed host call
     int knob_edge_percent = 88;             // UPX_EDGE_PERCENT: stream length of a fused launch's edge workgroups (100 = uniform)
+    int knob_zoom_once = 1;                 // UPX_ZOOM_ONCE: band-limited synthesis fills every workgroup slot once (0: UPX_ZOOM_FILL x slots)
+    int knob_zoom_edge_percent = 76;        // UPX_ZOOM_EDGE_PERCENT: length of the first / last synthesis stream of a signal (100 = like the others)
+    double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
     int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
     float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
     size_t seam_floats = 0;
@@ -408,6 +417,9 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_STREAM_CHUNK")) p->knob_stream_chunk = std::atoll(e);
     if (const char* e = std::getenv("UPX_EDGE_PERCENT")) p->knob_edge_percent = std::atoi(e);
     if (const char* e = std::getenv("UPX_PRIO_YOUNG")) p->knob_prio_young = std::atoi(e);
+    if (const char* e = std::getenv("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
+    if (const char* e = std::getenv("UPX_ZOOM_C_COST")) p->knob_zoom_c_cost = std::atof(e);
+    if (const char* e = std::getenv("UPX_ZOOM_EDGE_PERCENT")) p->knob_zoom_edge_percent = std::atoi(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         p->n_cu = prop.multiProcessorCount;
@@ -791,22 +803,98 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             // band-limited path: per launch pair, analysis of the frames of a run of streams, then their synthesis;
             // streams cover frames -1 .. m_hi-1 in runs of F (even); stream tails go through the seam buffer
             const long long frames = m_hi + 1;
-            const long long want = zoom_streams_wanted(p, s);
-            long long f = s.blocks_override > 0 ? s.blocks_override : (frames + want - 1) / want;
-            if (s.blocks_override <= 0) {
-                if (p->knob_zoom_f > 0) f = p->knob_zoom_f;   // experiments: frames per stream
-                else if (f < 16) f = 16;
-                // (longer streams balance worse than their fewer seams save: C4's synthesis 0.814 ms at 62 frames per stream,
-                // 0.769 at 48, 0.746 at 40 - where the fused launches of the same step give most of it back)
-                if (f > 48 && p->knob_zoom_f <= 0) f = 48;
-            }
-            if (f < s.k) f = s.k;
-            f += f & 1;
+            const long long pairs_total = (frames + 1) / 2;
             const int cap = zoom_frames_cap(p, s.zoom_p);
-            if (f > cap) f = cap;
-            const long long n_streams = (frames + f - 1) / f;
+            const int groups = s.zoom_d / s.zoom->rg;
+            const int res_s = zoom_resident(s);
             const long long tail = (long long)(s.k - 1) * s.hop;
-            const size_t seam_need = (size_t)n_streams * 3 * tail;
+            // Launch pairs (analysis, synthesis) and the streams of each: `cut` = pair index where a launch ends; the
+            // stream tables hold the first frame of every Ls/Rs stream and of every centre stream, launch after launch.
+            struct Launch { long long pair0, pair_end; int s0_lr, ns_lr, s0_c, ns_c; bool once; };
+            std::vector<Launch> launches;
+            std::vector<int> tab_lr, tab_c;
+            // n streams over n_pairs frame pairs, lengths within one pair of each other - except the stream that holds the
+            // signal's first frame and the one that holds its last: they run the synthesis' signal-edge flavour (per-sample
+            // checks on every transform: 15-25 % slower, scripts/phase_prof/zwgtime.hip) and get `edge` of the others' length
+            const double edge = p->knob_zoom_edge_percent >= 50 && p->knob_zoom_edge_percent < 100 ? p->knob_zoom_edge_percent / 100.0 : 1.0;
+            auto deal = [edge](std::vector<int>& tab, long long pair0, long long n_pairs, long long n, bool first, bool last,
+                               long long min_pairs) {
+                const double w_first = first && n >= 8 ? edge : 1.0, w_last = last && n >= 8 ? edge : 1.0;
+                const double total = (double)(n - 2) + w_first + w_last;
+                long long prev = 0;
+                for (long long i = 0; i < n; ++i) {
+                    const double before = i == 0 ? 0.0 : w_first + (double)(i - 1);
+                    long long q = n >= 8 ? (long long)((double)n_pairs * before / total) : n_pairs * i / n;
+                    if (i > 0 && q < prev + min_pairs) q = prev + min_pairs;   // (rounding; a stream holds a tail)
+                    tab.push_back((int)(-1 + 2 * (pair0 + q)));
+                    prev = q;
+                }
+            };
+            const bool once = p->knob_zoom_once != 0 && s.blocks_override <= 0 && p->knob_zoom_f <= 0;
+            if (once) {
+                // Every resident workgroup slot once (ZoomArgs): W workgroups per residue group, centre streams longer
+                // than the Ls/Rs ones by the ratio of what a frame costs either role, so that all end together.
+                const long long n_launch = (2 * pairs_total + cap - 1) / cap;
+                const long long W = (long long)p->n_cu * res_s / groups;
+                const double r = p->knob_zoom_c_cost > 0.05 && p->knob_zoom_c_cost < 1.0 ? p->knob_zoom_c_cost : 0.55;
+                const long long min_pairs = (s.k + 1) / 2 > 8 ? (s.k + 1) / 2 : 8;   // a stream holds a tail; short ones are all prologue
+                for (long long L = 0; L < n_launch; ++L) {
+                    const long long q0 = pairs_total * L / n_launch, q1 = pairs_total * (L + 1) / n_launch;
+                    const long long np = q1 - q0;
+                    long long n_c = (long long)std::llround((double)W * r / (1.0 + r)), n_lr = W - n_c;
+                    if (n_lr > np / min_pairs) n_lr = np / min_pairs;
+                    if (n_c > np / (2 * min_pairs)) n_c = np / (2 * min_pairs);
+                    if (n_lr < 1) n_lr = 1;
+                    if (n_c < 1) n_c = 1;
+                    launches.push_back(Launch{q0, q1, (int)tab_lr.size(), (int)n_lr, (int)tab_c.size(), (int)n_c,
+                                              (n_lr + n_c) * groups > (long long)p->n_cu * (res_s - 1)});
+                    deal(tab_lr, q0, np, n_lr, L == 0, L == n_launch - 1, min_pairs);
+                    deal(tab_c, q0, np, n_c, L == 0, L == n_launch - 1, min_pairs);
+                }
+            } else {
+                // streams of F frames for both roles, about UPX_ZOOM_FILL x the slots of them (the scheme of rounds 1-2;
+                // upx_plan_set_blocks_per_stream and UPX_ZOOM_F choose F)
+                const long long want = zoom_streams_wanted(p, s);
+                long long f = s.blocks_override > 0 ? s.blocks_override : (frames + want - 1) / want;
+                if (s.blocks_override <= 0) {
+                    if (p->knob_zoom_f > 0) f = p->knob_zoom_f;
+                    else if (f < 16) f = 16;
+                    if (f > 48 && p->knob_zoom_f <= 0) f = 48;
+                }
+                if (f < s.k) f = s.k;
+                f += f & 1;
+                if (f > cap) f = cap;
+                const long long n_streams = (frames + f - 1) / f, per_launch = cap / f;
+                for (long long s0 = 0; s0 < n_streams; s0 += per_launch) {
+                    const long long ns = n_streams - s0 < per_launch ? n_streams - s0 : per_launch;
+                    launches.push_back(Launch{s0 * f / 2, (s0 + ns) * f / 2, (int)s0, (int)ns, (int)s0, (int)ns, false});
+                    for (long long i = 0; i < ns; ++i) tab_lr.push_back((int)(-1 + (s0 + i) * f));
+                }
+                tab_c = tab_lr;
+            }
+            const int end_frame = (int)(-1 + 2 * launches.back().pair_end);
+            tab_lr.push_back(end_frame);
+            tab_c.push_back(end_frame);
+            const long long n_lr_total = (long long)tab_lr.size() - 1, n_c_total = (long long)tab_c.size() - 1;
+            // the tables live next to each other on the device; a repeated call on the same geometry sends nothing
+            s.h_m0 = tab_lr;
+            s.h_m0.insert(s.h_m0.end(), tab_c.begin(), tab_c.end());
+            if (s.h_m0.size() > s.m0_cap) {
+                HIP_TRY(hipStreamSynchronize(p->stream));
+                if (s.d_m0) HIP_TRY(hipFree(s.d_m0));
+                s.d_m0 = nullptr;
+                s.m0_cap = 0;
+                HIP_TRY(hipMalloc(&s.d_m0, s.h_m0.size() * sizeof(int)));
+                s.m0_cap = s.h_m0.size();
+                s.h_m0_sent.clear();
+            }
+            if (s.h_m0 != s.h_m0_sent) {
+                HIP_TRY(hipStreamSynchronize(p->stream));   // (the previous call's kernels read the old table)
+                HIP_TRY(hipMemcpyAsync(s.d_m0, s.h_m0.data(), s.h_m0.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
+                HIP_TRY(hipStreamSynchronize(p->stream));   // h_m0 may change before an asynchronous copy has read it
+                s.h_m0_sent = s.h_m0;
+            }
+            const size_t seam_need = (size_t)(2 * n_lr_total + n_c_total) * tail;
             if (seam_need > p->seam_floats) {
                 HIP_TRY(hipStreamSynchronize(p->stream));
                 if (p->d_seam) HIP_TRY(hipFree(p->d_seam));
@@ -821,31 +909,31 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
             a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw = s.d_tw; a.ramp = s.d_ramp;
             a.seam = p->d_seam;
+            a.seam_c = p->d_seam + (size_t)2 * n_lr_total * tail;
+            a.stream_m0 = s.d_m0;
+            a.stream_m0_c = s.d_m0 + n_lr_total + 1;
             a.n = s.n; a.d = s.zoom_d; a.hop = s.hop;
             a.t_in = (int)t_in; a.t_out = (int)t_out;
             a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
-            a.blocks_per_stream = (int)f;
+            a.blocks_per_stream = tab_lr[1] - tab_lr[0];
             a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
             a.accumulate = b == 0 ? 0 : 1;
-            const int groups = s.zoom_d / s.zoom->rg;
-            const long long streams_per_launch = cap / f;
             const long long slots = (long long)p->n_cu * zoom_resident(s, true);
             if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
-            const long long n_pairs_of_launches = (n_streams + streams_per_launch - 1) / streams_per_launch;
-            const bool split = p->timing && 2 * n_pairs_of_launches - 1 <= kMidEvents;
+            const bool split = p->timing && 2 * (long long)launches.size() - 1 <= kMidEvents;
             int n_mid = 0;
             hipEvent_t* mid = s.ring_mid.data() + (size_t)slot * kMidEvents;
             int n_launches = 0;
-            for (long long s0 = 0; s0 < n_streams; s0 += streams_per_launch, ++n_launches) {
-                const long long ns = n_streams - s0 < streams_per_launch ? n_streams - s0 : streams_per_launch;
-                a.stream0 = (int)s0;
-                a.f0 = (int)(-1 + s0 * f);
+            for (const Launch& L : launches) {
+                a.stream0 = L.s0_lr; a.ns_lr = L.ns_lr;
+                a.stream0_c = L.s0_c; a.ns_c = L.ns_c;
+                a.f0 = (int)(-1 + 2 * L.pair0);
+                a.pair0 = (int)L.pair0;
+                a.pair_end = (int)L.pair_end;
+                const long long pairs = L.pair_end - L.pair0;
                 a.y = p->d_zoom;
-                a.yc = p->d_zoom + (size_t)ns * f * s.zoom_p;
-                a.pair0 = (int)(s0 * f / 2);
-                a.pair_end = (int)((s0 + ns) * f / 2);
+                a.yc = p->d_zoom + (size_t)(2 * pairs) * s.zoom_p;
                 // analysis grid: every resident slot once, 8 x (workgroups per XCD label), see zoom_analysis_program
-                const long long pairs = a.pair_end - a.pair0;
                 long long per_xcd = (slots + 7) / 8;
                 if (per_xcd > (pairs + 7) / 8) per_xcd = (pairs + 7) / 8;
                 if (per_xcd < 1) per_xcd = 1;
@@ -855,24 +943,23 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                     a.prio_split = (p->knob_prio_young > 0 && res >= 2 && res <= 4 && 8 * per_xcd >= (long long)p->n_cu * res)
                                        ? p->n_cu : 0;
                     a.prio_rounds = res;
+                    // ... and so does the synthesis when its streams were cut for that
+                    a.prio_split_s = (p->knob_prio_young > 0 && L.once && res_s >= 2 && res_s <= 4) ? p->n_cu : 0;
+                    a.prio_rounds_s = res_s;
                 }
                 if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
                 s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
                 if (split) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
-                s.zoom->synthesis(a, (int)ns, groups, p->stream);
+                s.zoom->synthesis(a, groups, p->stream);
+                ++n_launches;
             }
             if (p->timing) s.ring_mid_n[slot] = n_mid;
-            if (n_streams > 1) {
-                upx::BandArgs sa;
-                std::memset(&sa, 0, sizeof sa);
-                sa.out_c = d_c; sa.out_l = d_l; sa.out_r = d_r;
-                sa.t_out = (int)t_out; sa.m_lo = 0; sa.m_hi = (int)m_hi; sa.blocks_per_stream = (int)f; sa.seam = p->d_seam;
-                hipLaunchKernelGGL(upx_stream_seam_add_kernel, dim3(grid_for(n_streams * tail)), dim3(256), 0, p->stream, sa,
-                                   (int)n_streams, (int)tail, s.hop);
-            }
+            if (n_lr_total > 1 || n_c_total > 1)
+                hipLaunchKernelGGL(upx_zoom_seam_add_kernel, dim3(grid_for((n_lr_total + n_c_total) * tail)), dim3(256), 0,
+                                   p->stream, a, (int)n_lr_total, (int)n_c_total, (int)tail);
             if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
-            s.last_wg = (int)(n_streams * groups * 2);
-            s.last_f = (int)f;
+            s.last_wg = (int)((n_lr_total + n_c_total) * groups);
+            s.last_f = tab_lr[1] - tab_lr[0];
             continue;
         }
         // blocks per stream: fill every resident workgroup slot once; even (whole frame pairs), at least 8 and at

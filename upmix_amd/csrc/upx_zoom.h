@@ -75,11 +75,46 @@ struct ZoomArgs {
     int pair0, pair_end;   // analysis launch: pairs [pair0, pair_end)
     int pairs_per_wg;      // analysis launch: workgroups per XCD (grid = 8 x this; see zoom_analysis_program)
     int stream0;           // synthesis launch: first stream
+    // Streams of the synthesis.  Ls/Rs stream sid transforms the frames [first, first + frames): uniform, first =
+    // m_lo - 1 + sid F with F = blocks_per_stream, or - stream_m0 != nullptr - [stream_m0[sid], stream_m0[sid + 1]) (odd
+    // starts, even lengths >= K).  The centre streams are cut independently (blocks_per_stream_c / stream_m0_c; Fc = 0 and
+    // no table: like the Ls/Rs streams): a centre transform serves two frames and costs about as much as an Ls/Rs one,
+    // so a centre stream of the same running time is about twice as long - which lets a launch fill every resident
+    // workgroup slot exactly once with workgroups that end together (upx_process_device), instead of dispatching a
+    // second and a third helping into slots that run dry one by one at the end (measured per workgroup,
+    // scripts/phase_prof/zwgtime.hip: 12 % of the synthesis' slot time).
+    // Tails: seam[sid][2][(K-1) hop] (Ls, Rs) and seam_c[sid][(K-1) hop].
+    int blocks_per_stream_c;   // Fc (even, >= K; 0: F)
+    const int* stream_m0;      // [Ls/Rs streams + 1]
+    const int* stream_m0_c;    // [centre streams + 1]
+    float* seam_c;
+    int stream0_c;             // synthesis launch: first centre stream
+    int ns_lr, ns_c;           // synthesis launch: streams of either role (grid = (ns_lr + ns_c) x residue groups)
+    // synthesis launch that fills every slot once: like the analysis below, a transform pair each (0: off)
+    int prio_split_s, prio_rounds_s;
     // analysis launch (every resident slot once, a static share of the pairs each): the workgroups that share a CU were
     // dispatched in `prio_rounds` rounds of `prio_split` and the hardware favours the older ones (BandArgs::prio_split);
     // they take the top priority in turn, a pair each.  0: off.
     int prio_split, prio_rounds;
 };
+
+// first frame / frames of synthesis stream sid of a role (0: Ls/Rs, 1: centre)
+UPX_HD int zoom_stream_first(const ZoomArgs& a, int role, int sid) {
+    const int* tab = role ? a.stream_m0_c : a.stream_m0;
+    if (tab) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return ((const UPX_GLOBAL int*)tab)[sid];
+#else
+        return tab[sid];
+#endif
+    }
+    return a.m_lo - 1 + sid * (role && a.blocks_per_stream_c > 0 ? a.blocks_per_stream_c : a.blocks_per_stream);
+}
+UPX_HD int zoom_stream_frames(const ZoomArgs& a, int role, int sid) {
+    if (role ? a.stream_m0_c != nullptr : a.stream_m0 != nullptr)
+        return zoom_stream_first(a, role, sid + 1) - zoom_stream_first(a, role, sid);
+    return role && a.blocks_per_stream_c > 0 ? a.blocks_per_stream_c : a.blocks_per_stream;
+}
 
 template <int LOG2P_, int RG_, int K_>
 struct ZoomCfg {
@@ -470,10 +505,13 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     // (SEEDS_LDS), because loads return in order
     constexpr bool AHEAD_OLD = Z::SEEDS_LDS;
     const int D = a.d;
-    const int F = a.blocks_per_stream;
-    const int sid = a.stream0 + stream_index;
-    const int m0 = a.m_lo - 1 + sid * F;
+    const int sid = (role ? a.stream0_c : a.stream0) + stream_index;
+    const int m0 = zoom_stream_first(a, role, sid);
+    const int F = zoom_stream_frames(a, role, sid);
     const int stride = D * SL;   // samples between slots
+    // position in the launch's dispatch order (upx_zoom_synthesis_kernel): Ls/Rs workgroups, then the centre ones
+    const int lin = role == 0 ? stream_index + a.ns_lr * grp : a.ns_lr * (D / RG) + stream_index + a.ns_c * grp;
+    (void)lin;
     const int n_tr = role == 0 ? F : F / 2;   // transforms of this stream: one per frame (Ls/Rs) or per pair (C)
 
     // Spectrum of transform t (nullptr: all zero).  Ls/Rs: frame m0 + t.  C: pair (m0 + 2t, m0 + 2t + 1), m0 odd.
@@ -614,6 +652,15 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     constexpr bool IN = decltype(in_tag)::value;      // interior stream: unconditional loads / stores
     constexpr bool ACC = decltype(acc_tag)::value;    // (interior only) the band accumulates onto the planes
     for (int t = 0; t < n_tr; ++t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (a.prio_split_s > 0 && (t & 1) == 0) {
+            const int r = (lin / a.prio_split_s + (t >> 1)) % a.prio_rounds_s;
+            if (r == 0) __builtin_amdgcn_s_setprio(3);
+            else if (r == 1) __builtin_amdgcn_s_setprio(2);
+            else if (r == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         const bool nonzero = IN || spec_of(t) != nullptr;
         ex.each([&, t, nonzero](int tid, Thread& th) {
             if (nonzero) {
@@ -754,12 +801,13 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     ex.each([&](int tid, Thread& th) {
         const int rho = tid % RG, sl = tid / RG;
         const size_t tail = (size_t)(Z::K - 1) * a.hop;
-        UPX_GLOBAL float* seam = opaque(a.seam) + (size_t)sid * 3 * tail + (D * sl + grp * RG + rho);
+        UPX_GLOBAL float* seam = (role ? opaque(a.seam_c) + (size_t)sid * tail : opaque(a.seam) + (size_t)sid * 2 * tail) +
+                                 (D * sl + grp * RG + rho);
 #pragma unroll
         for (int s = 0; s < 16 - HS; ++s) {
             if (role == 0) {
-                seam[1 * tail + (size_t)s * stride] = th.acc_rl[s].y;
-                seam[2 * tail + (size_t)s * stride] = th.acc_rl[s].x;
+                seam[(size_t)s * stride] = th.acc_rl[s].y;
+                seam[tail + (size_t)s * stride] = th.acc_rl[s].x;
             } else {
                 seam[(size_t)s * stride] = th.acc_c[s];
             }
@@ -772,6 +820,26 @@ template <class Z, class Ex>
 UPX_HD void zoom_synthesis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int stream_index, int grp, int role) {
     if (role == 0) zoom_synthesis_role<Z, 0>(ex, a, lds_all, stream_index, grp);
     else zoom_synthesis_role<Z, 1>(ex, a, lds_all, stream_index, grp);
+}
+
+// The tails of the band-limited streams onto the first blocks of their successors (stream_seam_add of upx_core.h for
+// the two stream lists): gid < n_lr tail: Ls / Rs of stream gid / tail, above that the centre streams.
+UPX_HD void zoom_seam_add(const ZoomArgs& a, int n_lr, int n_c, int tail, long long gid) {
+    const int role = gid >= (long long)n_lr * tail ? 1 : 0;
+    if (role) gid -= (long long)n_lr * tail;
+    const int sid = (int)(gid / tail), i = (int)(gid % tail);
+    if (sid >= (role ? n_c : n_lr) - 1) return;             // the last stream's tail lies beyond the emitted range
+    const long long m = zoom_stream_first(a, role, sid + 1);
+    const long long n = m * a.hop + i;
+    if (m >= a.m_hi || n < 0 || n >= a.t_out) return;
+    if (m + i / a.hop >= a.m_hi) return;                    // blocks past the emitted range stay untouched
+    if (role) {
+        a.out_c[n] += a.seam_c[(size_t)sid * tail + i];
+    } else {
+        const float* row = a.seam + (size_t)sid * 2 * tail;
+        a.out_l[n] += row[i];
+        a.out_r[n] += row[tail + i];
+    }
 }
 
 // Host-side helper: the ramp seeds of zoom_ramp, [D][P/16 + 4] (double precision -> float).
