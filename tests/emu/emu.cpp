@@ -314,6 +314,10 @@ extern "C" int emu_pipeline(long long n_items, long long fail_submit, long long 
 
 // ---- band-limited ("zoom") path: analysis kernel, synthesis kernel, stream seams (upx_zoom.h) ------------
 namespace {
+// pairs of the analysis dealt by age (ZoomArgs::deal_rows), set by emu_zoom_set_deal for the calls that follow
+int g_deal_rows = 0;
+std::vector<int> g_deal_tab;
+
 // streams: uniform (blocks_per_stream for both roles, or F / c_split for the centre), or - tab_lr != nullptr - the two
 // tables of first frames (n + 1 entries each; ZoomArgs::stream_m0 / stream_m0_c)
 template <class Z>
@@ -364,6 +368,8 @@ int run_zoom(upx::ZoomArgs a, int pairs_per_wg, int c_split, const int* tab_lr =
     a.pair0 = a.m_lo / 2;
     a.pair_end = a.pair0 + n_frames / 2;
     a.pairs_per_wg = pairs_per_wg;   // workgroups per XCD label: the grid is 8 x this
+    a.deal_rows = (int)g_deal_tab.size() == 2 * pairs_per_wg ? g_deal_rows : 0;
+    a.deal_tab = g_deal_tab.data();
     for (int wg = 0; wg < 8 * pairs_per_wg; ++wg) {
         WaveExec<16> ex;
         ex.st.resize(Z::WG);
@@ -385,6 +391,11 @@ int run_zoom(upx::ZoomArgs a, int pairs_per_wg, int c_split, const int* tab_lr =
     return 0;
 }
 }   // namespace
+
+extern "C" void emu_zoom_set_deal(int rows, const int* tab, int n_l) {   // tab: [n_l][2] (ZoomArgs::deal_tab)
+    g_deal_rows = rows;
+    g_deal_tab.assign(tab, tab + (rows > 0 ? 2 * n_l : 0));
+}
 
 extern "C" int emu_zoom_band_streams(int log2n, int k_overlap, int log2p, const float* in, long long t_in, float* out_c,
                                      float* out_l, float* out_r, long long t_out, const float* w_a, const float* w_s_scaled,

@@ -23,6 +23,8 @@ def emu():
     ip = ctypes.POINTER(ctypes.c_int)
     lib.emu_zoom_band_streams.argtypes = lib.emu_zoom_band.argtypes + [ctypes.c_int, ip, ctypes.c_int, ip, ctypes.c_int]
     lib.emu_zoom_band_streams.restype = ctypes.c_int
+    lib.emu_zoom_set_deal.argtypes = [ctypes.c_int, ip, ctypes.c_int]
+    lib.emu_zoom_set_deal.restype = None
     return lib
 
 
@@ -195,6 +197,35 @@ def test_stream_tables_one_workgroup_per_slot(emu):
     # a table that does not cover the frames, or holds an odd length, is refused by the emulator's driver
     with pytest.raises(AssertionError):
         run_zoom(emu, band, x, 1000, tables=([-1, 8, 2 * pairs - 1], [-1, 2 * pairs - 1]))
+
+
+def test_analysis_pairs_dealt_by_age_change_nothing(emu):
+    """ZoomArgs::deal_rows: the XCD's workgroups take unequal numbers of pairs (rows of n_l, then runs of consecutive
+    pairs).  Every pair is still transformed exactly once, so the planes do not change by a bit; a dealing that leaves
+    pairs out shows up as NaN (the emulator poisons the spectra)."""
+    band = orc.Band(4096, 0.75, 480., 1920., 48000, "raised_cosine", 120., 480.)
+    x = orc.synthetic_stereo(200000, 5)     # one stream of 200 frames -> 100 pairs -> 13 per XCD share
+    base = run_zoom(emu, band, x, 200, pairs_per_wg=3)
+
+    def deal(rows, extras):
+        tab, behind = [], 0
+        for n in extras:
+            tab += [behind, n]
+            behind += n
+        emu.emu_zoom_set_deal(rows, (ctypes.c_int * len(tab))(*tab), len(extras))
+
+    try:
+        for rows, extras in ((3, [3, 1, 0]), (2, [3, 2, 2]), (1, [5, 3, 2]), (4, [1, 0, 0]), (1, [10, 0, 0])):
+            assert rows * 3 + sum(extras) >= 13
+            deal(rows, extras)
+            got = run_zoom(emu, band, x, 200, pairs_per_wg=3)
+            for a, b in zip(base, got):
+                assert np.array_equal(a, b), (rows, extras)
+        deal(3, [1, 0, 0])   # too few pairs dealt: spectra left unwritten
+        got = run_zoom(emu, band, x, 200, pairs_per_wg=3)
+        assert any(np.isnan(g).any() for g in got)
+    finally:
+        emu.emu_zoom_set_deal(0, (ctypes.c_int * 2)(), 0)
 
 
 def test_band_accumulation_and_merged_gain_list(emu):

@@ -207,6 +207,13 @@ struct BandState {
     float* d_gain = nullptr;   // 0.5 * gain
     upx::cf* d_tw = nullptr;   // shared per N (owned by plan->tw)
     int blocks_override = 0;
+    // band-limited analysis: pairs dealt by workgroup age (ZoomArgs::deal_rows), cached per launch geometry
+    struct Deal {
+        long long key = -1;
+        int rows = 0;
+        int* d_tab = nullptr;
+    };
+    std::vector<Deal> deals;
     // streams of unequal length (BandArgs::stream_m0): the table of the last geometry, on the host and on the device
     std::vector<int> h_m0, h_m0_sent;
     int* d_m0 = nullptr;
@@ -242,6 +249,7 @@ struct upx_plan {
     long long knob_stream_chunk = 1LL << 22;   // UPX_STREAM_CHUNK: owned samples per chunk of a streamed host call
     int knob_edge_percent = 88;             // UPX_EDGE_PERCENT: stream length of a fused launch's edge workgroups (100 = uniform)
     int knob_zoom_once = 1;                 // UPX_ZOOM_ONCE: band-limited synthesis fills every workgroup slot once (0: UPX_ZOOM_FILL x slots)
+    int knob_zoom_a_age = 8;                // UPX_ZOOM_A_AGE: % by which each later dispatch round of the band-limited analysis runs slower (0 = equal shares)
     int knob_zoom_edge_percent = 76;        // UPX_ZOOM_EDGE_PERCENT: length of the first / last synthesis stream of a signal (100 = like the others)
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
     int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
@@ -420,6 +428,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
     if (const char* e = std::getenv("UPX_ZOOM_C_COST")) p->knob_zoom_c_cost = std::atof(e);
     if (const char* e = std::getenv("UPX_ZOOM_EDGE_PERCENT")) p->knob_zoom_edge_percent = std::atoi(e);
+    if (const char* e = std::getenv("UPX_ZOOM_A_AGE")) p->knob_zoom_a_age = std::atoi(e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         p->n_cu = prop.multiProcessorCount;
@@ -656,6 +665,7 @@ void upx_plan_destroy(upx_plan* p) {
         if (s.d_tw_n) (void)hipFree(s.d_tw_n);
         if (s.d_ramp) (void)hipFree(s.d_ramp);
         if (s.d_m0) (void)hipFree(s.d_m0);
+        for (auto& d : s.deals) (void)hipFree(d.d_tab);
         for (auto e : s.ring0) if (e) (void)hipEventDestroy(e);
         for (auto e : s.ring1) if (e) (void)hipEventDestroy(e);
         for (auto e : s.ring_mid) if (e) (void)hipEventDestroy(e);
@@ -943,6 +953,57 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                     a.prio_split = (p->knob_prio_young > 0 && res >= 2 && res <= 4 && 8 * per_xcd >= (long long)p->n_cu * res)
                                        ? p->n_cu : 0;
                     a.prio_rounds = res;
+                    // ... and the older workgroups, which still end first, take more pairs (ZoomArgs::deal_rows)
+                    a.deal_rows = 0;
+                    const long long np_xcd = (pairs + 7) / 8;      // pairs of an XCD's share (zoom_analysis_program)
+                    if (a.prio_split > 0 && p->knob_zoom_a_age > 0 && p->knob_zoom_a_age < 40 && np_xcd >= 4 * per_xcd) {
+                        const long long key = np_xcd * 4096 + per_xcd * 8 + res;
+                        const BandState::Deal* deal = nullptr;
+                        for (const auto& d : s.deals)
+                            if (d.key == key) deal = &d;
+                        if (!deal) {
+                            // pair after pair to the workgroup that would end first: round r of the `res` dispatch
+                            // rounds runs at 1 - r age of the first round's speed; ties go to the older workgroup, so
+                            // the counts never increase with l
+                            const int n_l = (int)per_xcd, per_round = n_l / res;
+                            std::vector<int> count(n_l, 0);
+                            std::vector<double> cost(n_l);
+                            for (int l = 0; l < n_l; ++l) {
+                                const int r = l / per_round < res ? l / per_round : res - 1;
+                                cost[l] = 1.0 / (1.0 - r * p->knob_zoom_a_age / 100.0);
+                            }
+                            for (long long k = 0; k < np_xcd; ++k) {
+                                int best = 0;
+                                double t_best = 1e300;
+                                for (int l = 0; l < n_l; ++l) {
+                                    const double t = (count[l] + 1) * cost[l];
+                                    if (t < t_best - 1e-9) { t_best = t; best = l; }
+                                }
+                                ++count[best];
+                            }
+                            BandState::Deal d;
+                            d.key = key;
+                            d.rows = count[n_l - 1];
+                            std::vector<int> tab(2 * (size_t)n_l);
+                            int behind = 0;
+                            for (int l = 0; l < n_l; ++l) {
+                                tab[2 * l] = behind;
+                                tab[2 * l + 1] = count[l] - d.rows;
+                                behind += tab[2 * l + 1];
+                            }
+                            if (s.deals.size() >= 8) {   // (geometries come and go: start over)
+                                HIP_TRY(hipStreamSynchronize(p->stream));
+                                for (auto& old : s.deals) (void)hipFree(old.d_tab);
+                                s.deals.clear();
+                            }
+                            HIP_TRY(hipMalloc(&d.d_tab, tab.size() * sizeof(int)));
+                            HIP_TRY(hipMemcpy(d.d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+                            s.deals.push_back(d);
+                            deal = &s.deals.back();
+                        }
+                        a.deal_rows = deal->rows;
+                        a.deal_tab = deal->d_tab;
+                    }
                     // ... and so does the synthesis when its streams were cut for that
                     a.prio_split_s = (p->knob_prio_young > 0 && L.once && res_s >= 2 && res_s <= 4) ? p->n_cu : 0;
                     a.prio_rounds_s = res_s;

@@ -96,6 +96,12 @@ struct ZoomArgs {
     // dispatched in `prio_rounds` rounds of `prio_split` and the hardware favours the older ones (BandArgs::prio_split);
     // they take the top priority in turn, a pair each.  0: off.
     int prio_split, prio_rounds;
+    // ... and with the turns the older workgroups still end first.  deal_rows > 0: the XCD's l-th workgroup takes pair l
+    // of each of the first deal_rows rows of n_l pairs, then deal_tab[l][1] consecutive pairs that start deal_tab[l][0]
+    // pairs behind those rows: low l = dispatched first = older = faster, so they are dealt more and all end together
+    // (upx_process_device deals by age).  0: rows of n_l pairs until the XCD's share ends.
+    int deal_rows;
+    const int* deal_tab;   // [n_l][2]
 };
 
 // first frame / frames of synthesis stream sid of a role (0: Ls/Rs, 1: centre)
@@ -288,6 +294,26 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
     int q_stop = a.pair0 + (xcd + 1) * per_xcd;
     if (q_stop > a.pair_end) q_stop = a.pair_end;
 
+    // the pair after q for this workgroup (>= q_stop: none); see ZoomArgs::deal_rows
+    const int q_base = a.pair0 + xcd * per_xcd;
+    int extra_first = 0, extra_end = 0;   // this workgroup's consecutive pairs behind the rows, relative to q_base
+    const int rect = a.deal_rows * n_l;
+    if (a.deal_rows > 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const UPX_GLOBAL int* tab = (const UPX_GLOBAL int*)a.deal_tab;
+#else
+        const int* tab = a.deal_tab;
+#endif
+        extra_first = rect + tab[2 * l];
+        extra_end = extra_first + tab[2 * l + 1];
+    }
+    auto next_q = [&](int q) {
+        if (a.deal_rows <= 0) return q + n_l;
+        const int loc = q - q_base;
+        if (loc + n_l < rect) return q + n_l;                                             // the next row
+        if (loc < rect) return extra_first < extra_end ? q_base + extra_first : q_stop;   // the last row: on to the extras
+        return loc + 1 < extra_end ? q + 1 : q_stop;
+    };
     struct Unit {
         int q, half, grp;
     };
@@ -303,7 +329,7 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
             }
             u.grp = -1;   // next frame, group 0 (if the frame exists)
             if (u.half == 0) u.half = 1;
-            else { u.half = 0; u.q += n_l; }
+            else { u.half = 0; u.q = next_q(u.q); }
             if (u.q >= q_stop) return u;
             if (exists(frame_of(u))) {
                 u.grp = 0;
@@ -339,14 +365,14 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
         }
     };
 
-    Unit cur{a.pair0 + xcd * per_xcd + l, 0, -1};
+    Unit cur{q_base + l, 0, -1};
     if (cur.q < q_stop && exists(frame_of(cur))) cur.grp = 0;
     else cur = advance(cur);
     if (Z::PREFETCH_A && cur.q < q_stop) ex.each([&, cur](int tid, Thread& th) { request(tid, th, cur); });
 
     // frames are visited pair by pair; a pair whose frames do not exist still writes its (zero) centre spectrum
     int turn = 0;
-    for (int q = a.pair0 + xcd * per_xcd + l; q < q_stop; q += n_l, ++turn) {
+    for (int q = q_base + l; q < q_stop; q = next_q(q), ++turn) {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (a.prio_split > 0) {
             const int r = (wg_index / a.prio_split + turn) % a.prio_rounds;
