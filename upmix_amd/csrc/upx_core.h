@@ -97,7 +97,48 @@ UPX_HD cf fma_swapz_sub(cf z, cf g, cf u) {   // swap(g.x z) - u = (g.x z.y - u.
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(t) : "v"(z), "v"(g), "v"(u));
     return t;
 }
+// c + a b and 2 p - t: a twiddled butterfly (p + w q, p - w q) is cfma and twice_minus, three instructions for the pair
+// where multiply, add and subtract take four (the difference comes back from the sum: p - w q = 2 p - (p + w q))
+UPX_HD cf cfma(cf a, cf b, cf c) {
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(t)
+        : "v"(a), "v"(b), "v"(c));
+    return t;
+}
+UPX_HD cf twice_minus(cf p, cf t) {   // (the inline constant is the low half: both result halves select it)
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(p), "v"(t));
+    return r;
+}
+// the same with a compile-time constant b: it lives in a scalar register pair (one scalar source per instruction),
+// not in two vector registers that the allocator would have to keep or rebuild
+UPX_HD cf cmul_k(cf a, cf b) {
+    cf t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(t)
+        : "v"(a), "s"(b));
+    return t;
+}
+UPX_HD cf cfma_k(cf a, cf b, cf c) {
+    cf t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(t)
+        : "v"(a), "s"(b), "v"(c));
+    return t;
+}
 #else
+UPX_HD cf cmul_k(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+UPX_HD cf cfma_k(cf a, cf b, cf c) {
+    return mk(__builtin_fmaf(-a.y, b.y, __builtin_fmaf(a.x, b.x, c.x)), __builtin_fmaf(a.y, b.x, __builtin_fmaf(a.x, b.y, c.y)));
+}
+UPX_HD cf cfma(cf a, cf b, cf c) {
+    return mk(__builtin_fmaf(-a.y, b.y, __builtin_fmaf(a.x, b.x, c.x)), __builtin_fmaf(a.y, b.x, __builtin_fmaf(a.x, b.y, c.y)));
+}
+UPX_HD cf twice_minus(cf p, cf t) { return mk(__builtin_fmaf(2.0f, p.x, -t.x), __builtin_fmaf(2.0f, p.y, -t.y)); }
 UPX_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 UPX_HD cf add_mi(cf a, cf b) { return mk(a.x + b.y, a.y - b.x); }
 UPX_HD cf sub_mi(cf a, cf b) { return mk(a.x - b.y, a.y + b.x); }
@@ -268,6 +309,40 @@ UPX_HD void dft4_mi2(cf& a0, cf& a1, cf& a2, cf& a3) {
     a3 = sub_mi(t1, d);
 }
 
+// UPX_FMA_BUTTERFLY: twiddled butterflies in the multiply-add form (cfma / twice_minus)
+#if !defined(UPX_FMA_BUTTERFLY)
+#define UPX_FMA_BUTTERFLY 1
+#endif
+// dft4 of (a0 [w0], a1 w1, a2 w2, a3 w3); W0: a0 carries a twiddle as well.  MI2: w2 = -i (not passed)
+// KONST: the twiddles are compile-time constants (scalar registers)
+template <bool W0, bool MI2 = false, bool KONST = false>
+UPX_HD void dft4_tw(cf& a0, cf& a1, cf& a2, cf& a3, cf w0, cf w1, cf w2, cf w3) {
+#if UPX_FMA_BUTTERFLY
+    const cf p0 = W0 ? (KONST ? cmul_k(a0, w0) : cmul(a0, w0)) : a0;
+    cf t0, t1;
+    if constexpr (MI2) {
+        t0 = add_mi(p0, a2);
+        t1 = sub_mi(p0, a2);
+    } else {
+        t0 = KONST ? cfma_k(a2, w2, p0) : cfma(a2, w2, p0);
+        t1 = twice_minus(p0, t0);
+    }
+    const cf p1 = KONST ? cmul_k(a1, w1) : cmul(a1, w1);
+    const cf t2 = KONST ? cfma_k(a3, w3, p1) : cfma(a3, w3, p1), d = twice_minus(p1, t2);
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = add_mi(t1, d);
+    a3 = sub_mi(t1, d);
+#else
+    if (W0) a0 = cmul(a0, w0);
+    a1 = cmul(a1, w1);
+    if (!MI2) a2 = cmul(a2, w2);
+    a3 = cmul(a3, w3);
+    if (MI2) dft4_mi2(a0, a1, a2, a3);
+    else dft4(a0, a1, a2, a3);
+#endif
+}
+
 // multiply by W8^1 = (1 - i)/sqrt2 and W8^3 = (-1 - i)/sqrt2
 UPX_HD cf mul_w8_1(cf a) { return scale(add_mi(a, a), kSqrtHalf); }    // (x + y, y - x) / sqrt2
 UPX_HD cf mul_w8_3(cf a) { return scale(sub_mi(a, a), -kSqrtHalf); }   // -(x - y, y + x) / sqrt2
@@ -350,9 +425,20 @@ UPX_HD void dft4_p(cf& a0, cf& a1, cf& a2, cf& a3) {
 template <int R>
 struct Dft;
 
+// run_tw(v, w): the DFT of (v[0], v[1] w[1], ..., v[R-1] w[R-1]) - a pass's twiddles folded into the first butterflies
 template <>
 struct Dft<2> {
     static UPX_HD void run(cf* v) { dft2(v[0], v[1]); }
+    static UPX_HD void run_tw(cf* v, const cf* w) {
+#if UPX_FMA_BUTTERFLY
+        const cf t = cfma(v[1], w[1], v[0]);
+        v[1] = twice_minus(v[0], t);
+        v[0] = t;
+#else
+        v[1] = cmul(v[1], w[1]);
+        run(v);
+#endif
+    }
     template <unsigned IM, unsigned OM>
     static UPX_HD void run_p(cf* v) {
         constexpr bool l0 = bit(IM, 0), l1 = bit(IM, 1);
@@ -364,11 +450,28 @@ struct Dft<2> {
 template <>
 struct Dft<4> {
     static UPX_HD void run(cf* v) { dft4(v[0], v[1], v[2], v[3]); }
+    static UPX_HD void run_tw(cf* v, const cf* w) { dft4_tw<false>(v[0], v[1], v[2], v[3], w[0], w[1], w[2], w[3]); }
     template <unsigned IM, unsigned OM>
     static UPX_HD void run_p(cf* v) { dft4_p<IM, OM>(v[0], v[1], v[2], v[3]); }
 };
 template <>
 struct Dft<8> {
+    static UPX_HD void run_tw(cf* v, const cf* w) {
+        // first stage: the two DFT4 over a take inputs (0, 2, 4, 6) and (1, 3, 5, 7)
+        cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+        cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+        dft4_tw<false>(e0, e1, e2, e3, w[0], w[2], w[4], w[6]);
+        dft4_tw<true>(o0, o1, o2, o3, w[1], w[3], w[5], w[7]);
+        second(v, e0, e1, e2, e3, o0, o1, o2, o3);
+    }
+    static UPX_HD void second(cf* v, cf e0, cf e1, cf e2, cf e3, cf o0, cf o1, cf o2, cf o3) {
+        o1 = mul_w8_1(o1);
+        o3 = mul_w8_3(o3);
+        v[0] = e0 + o0; v[4] = e0 - o0;
+        v[1] = e1 + o1; v[5] = e1 - o1;
+        v[2] = add_mi(e2, o2); v[6] = sub_mi(e2, o2);   // o2 * (-i)
+        v[3] = e3 + o3; v[7] = e3 - o3;
+    }
     // n = 2a + b: two DFT4 over a, twiddle W8^(b k1), DFT2 over b
     static UPX_HD void run(cf* v) {
         cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
@@ -410,6 +513,31 @@ struct Dft<8> {
 };
 template <>
 struct Dft<16> {
+    // the second stage: DFT4 over b of W16^(b k1) y[b][k1]; the constants ride on the butterflies (dft4_tw)
+    static UPX_HD void second(cf* v, cf (&y)[4][4]) {
+        const cf w1 = mk(kC16, -kS16), w2 = mk(kSqrtHalf, -kSqrtHalf), w3 = mk(kS16, -kC16);
+        const cf w6 = mk(-kSqrtHalf, -kSqrtHalf), w9 = mk(-kC16, kS16), one = mk(1.f, 0.f);
+        dft4(y[0][0], y[1][0], y[2][0], y[3][0]);
+        dft4_tw<false, false, true>(y[0][1], y[1][1], y[2][1], y[3][1], one, w1, w2, w3);
+        dft4_tw<false, true, true>(y[0][2], y[1][2], y[2][2], y[3][2], one, w2, one, w6);   // W16^4 = -i inside
+        dft4_tw<false, false, true>(y[0][3], y[1][3], y[2][3], y[3][3], one, w3, w6, w9);
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            v[k1] = y[0][k1]; v[k1 + 4] = y[1][k1]; v[k1 + 8] = y[2][k1]; v[k1 + 12] = y[3][k1];
+        }
+    }
+    static UPX_HD void run_tw(cf* v, const cf* w) {
+        cf y[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            y[b][0] = v[b]; y[b][1] = v[4 + b]; y[b][2] = v[8 + b]; y[b][3] = v[12 + b];
+        }
+        dft4_tw<false>(y[0][0], y[0][1], y[0][2], y[0][3], w[0], w[4], w[8], w[12]);
+        dft4_tw<true>(y[1][0], y[1][1], y[1][2], y[1][3], w[1], w[5], w[9], w[13]);
+        dft4_tw<true>(y[2][0], y[2][1], y[2][2], y[2][3], w[2], w[6], w[10], w[14]);
+        dft4_tw<true>(y[3][0], y[3][1], y[3][2], y[3][3], w[3], w[7], w[11], w[15]);
+        second(v, y);
+    }
     // n = 4a + b, k = k1 + 4 k2:  X[k1+4k2] = DFT4_b( W16^(b k1) * DFT4_a(v[4a+b])[k1] )[k2]
     static UPX_HD void run(cf* v) {
         cf y[4][4];
@@ -418,6 +546,10 @@ struct Dft<16> {
             y[b][0] = v[b]; y[b][1] = v[4 + b]; y[b][2] = v[8 + b]; y[b][3] = v[12 + b];
             dft4(y[b][0], y[b][1], y[b][2], y[b][3]);
         }
+#if UPX_FMA_BUTTERFLY
+        second(v, y);
+        return;
+#endif
         const cf w1 = mk(kC16, -kS16), w3 = mk(kS16, -kC16);
         y[1][1] = cmul(y[1][1], w1);
         y[1][2] = mul_w8_1(y[1][2]);
@@ -717,10 +849,14 @@ struct Stream {
                 for (int r = 0; r < R; ++r) v[r] = th.x[q + r * NB];
                 if (NS > 1) {
                     const cf* row = tw + OFF + ((lane + q * LANES) & (NS - 1));
+                    cf w[R];
+                    w[0] = mk(1.f, 0.f);
 #pragma unroll
-                    for (int r = 1; r < R; ++r) v[r] = cmul(v[r], lds_load(row + (r - 1) * NS));
+                    for (int r = 1; r < R; ++r) w[r] = lds_load(row + (r - 1) * NS);
+                    Dft<R>::run_tw(v, w);
+                } else {
+                    Dft<R>::run(v);
                 }
-                Dft<R>::run(v);
 #pragma unroll
                 for (int r = 0; r < R; ++r) th.x[q + r * NB] = v[r];
             }
@@ -845,13 +981,11 @@ struct Stream {
             }
             UPX_SCHED_FENCE();
             if (NS > 1) {
-#pragma unroll
-                for (int i = 1; i < P; ++i) {
-                    const int r = (i & 3) * 4 + (i >> 2);
-                    th.x[r] = cmul(th.x[r], w[r]);
-                }
+                w[0] = mk(1.f, 0.f);
+                Dft<P>::run_tw(th.x, w);
+            } else {
+                Dft<P>::run(th.x);
             }
-            Dft<P>::run(th.x);
         } else {
             read_all(th, lds, lane);
             pass_compute<PI>(th, tw, lane);
