@@ -343,6 +343,22 @@ UPX_HD void dft4_tw(cf& a0, cf& a1, cf& a2, cf& a3, cf w0, cf w1, cf w2, cf w3) 
 #endif
 }
 
+// dft4 of (s0 a0, s1 a1, s2 a2, s3 a3) with real factors (a window): the products ride on the first butterflies
+UPX_HD void dft4_sc(cf& a0, cf& a1, cf& a2, cf& a3, float s0, float s1, float s2, float s3) {
+#if UPX_FMA_BUTTERFLY
+    const cf p0 = scale(a0, s0), p1 = scale(a1, s1);
+    const cf t0 = scale(a2, s2) + p0, t2 = scale(a3, s3) + p1;   // (contracted: one packed multiply-add each)
+    const cf t1 = twice_minus(p0, t0), d = twice_minus(p1, t2);
+    a0 = t0 + t2;
+    a2 = t0 - t2;
+    a1 = add_mi(t1, d);
+    a3 = sub_mi(t1, d);
+#else
+    a0 = scale(a0, s0); a1 = scale(a1, s1); a2 = scale(a2, s2); a3 = scale(a3, s3);
+    dft4(a0, a1, a2, a3);
+#endif
+}
+
 // multiply by W8^1 = (1 - i)/sqrt2 and W8^3 = (-1 - i)/sqrt2
 UPX_HD cf mul_w8_1(cf a) { return scale(add_mi(a, a), kSqrtHalf); }    // (x + y, y - x) / sqrt2
 UPX_HD cf mul_w8_3(cf a) { return scale(sub_mi(a, a), -kSqrtHalf); }   // -(x - y, y + x) / sqrt2
@@ -465,12 +481,17 @@ struct Dft<8> {
         second(v, e0, e1, e2, e3, o0, o1, o2, o3);
     }
     static UPX_HD void second(cf* v, cf e0, cf e1, cf e2, cf e3, cf o0, cf o1, cf o2, cf o3) {
+        v[0] = e0 + o0; v[4] = e0 - o0;
+        v[2] = add_mi(e2, o2); v[6] = sub_mi(e2, o2);   // o2 * (-i)
+#if UPX_FMA_BUTTERFLY
+        v[1] = cfma_k(o1, mk(kSqrtHalf, -kSqrtHalf), e1); v[5] = twice_minus(e1, v[1]);
+        v[3] = cfma_k(o3, mk(-kSqrtHalf, -kSqrtHalf), e3); v[7] = twice_minus(e3, v[3]);
+#else
         o1 = mul_w8_1(o1);
         o3 = mul_w8_3(o3);
-        v[0] = e0 + o0; v[4] = e0 - o0;
         v[1] = e1 + o1; v[5] = e1 - o1;
-        v[2] = add_mi(e2, o2); v[6] = sub_mi(e2, o2);   // o2 * (-i)
         v[3] = e3 + o3; v[7] = e3 - o3;
+#endif
     }
     // n = 2a + b: two DFT4 over a, twiddle W8^(b k1), DFT2 over b
     static UPX_HD void run(cf* v) {
@@ -478,12 +499,7 @@ struct Dft<8> {
         cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
         dft4(e0, e1, e2, e3);
         dft4(o0, o1, o2, o3);
-        o1 = mul_w8_1(o1);
-        o3 = mul_w8_3(o3);
-        v[0] = e0 + o0; v[4] = e0 - o0;
-        v[1] = e1 + o1; v[5] = e1 - o1;
-        v[2] = add_mi(e2, o2); v[6] = sub_mi(e2, o2);   // o2 * (-i)
-        v[3] = e3 + o3; v[7] = e3 - o3;
+        second(v, e0, e1, e2, e3, o0, o1, o2, o3);
     }
     template <unsigned IM, unsigned OM>
     static UPX_HD void run_p(cf* v) {
@@ -525,6 +541,29 @@ struct Dft<16> {
         for (int k1 = 0; k1 < 4; ++k1) {
             v[k1] = y[0][k1]; v[k1 + 4] = y[1][k1]; v[k1 + 8] = y[2][k1]; v[k1 + 12] = y[3][k1];
         }
+    }
+    // run_sc in two steps, in place: first_sc leaves y[b][k1] in v[4 k1 + b], second_inplace finishes
+    static UPX_HD void first_sc(cf* v, const float* s) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dft4_sc(v[b], v[4 + b], v[8 + b], v[12 + b], s[b], s[4 + b], s[8 + b], s[12 + b]);
+    }
+    static UPX_HD void second_inplace(cf* v) {
+        cf y[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            y[b][0] = v[b]; y[b][1] = v[4 + b]; y[b][2] = v[8 + b]; y[b][3] = v[12 + b];
+        }
+        second(v, y);
+    }
+    // the DFT of (s[0] v[0], ..., s[15] v[15]), s real
+    static UPX_HD void run_sc(cf* v, const float* s) {
+        cf y[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            y[b][0] = v[b]; y[b][1] = v[4 + b]; y[b][2] = v[8 + b]; y[b][3] = v[12 + b];
+            dft4_sc(y[b][0], y[b][1], y[b][2], y[b][3], s[b], s[4 + b], s[8 + b], s[12 + b]);
+        }
+        second(v, y);
     }
     static UPX_HD void run_tw(cf* v, const cf* w) {
         cf y[4][4];
@@ -1199,6 +1238,8 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
             for (int s = 0; s < P; ++s) wa[s] = gat(w_a, (unsigned)lane, s * LANES);
         }
+        // (the window folded into pass 0's first butterflies - Dft<16>::run_sc, as the band-limited analysis does - made
+        // these kernels 0-2 % slower: not used here)
         if (hr.fast) {
 #pragma unroll
             for (int s = 0; s < P; ++s) th.x[s] = scale(s < P - HS ? hr.v[s] : th.pre[s < P - HS ? 0 : s - (P - HS)], wa[s]);

@@ -392,8 +392,10 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
                     ex.each([&, q, half, grp, nxt, last_group](int tid, Thread& th) {
                         const int rho = tid % RG, sl = tid / RG;
                         if constexpr (Z::PREFETCH_A) {
+                            // window and the first butterflies of pass 0 in one (the prefetch below reuses th.pre / th.acc_c)
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) th.x[s] = scale(th.pre[s], th.acc_c[s]);
+                            for (int s = 0; s < 16; ++s) th.x[s] = UPX_FMA_BUTTERFLY ? th.pre[s] : scale(th.pre[s], th.acc_c[s]);
+                            if constexpr (UPX_FMA_BUTTERFLY != 0) Dft<16>::first_sc(th.x, th.acc_c);
                         }
                         // short loads of this unit first ...
                         if constexpr (Z::PREFETCH_A) {
@@ -421,10 +423,13 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
                         } else {
                             request(tid, th, Unit{q, half, grp});
 #pragma unroll
-                            for (int s = 0; s < 16; ++s) th.x[s] = scale(th.pre[s], th.acc_c[s]);
+                            for (int s = 0; s < 16; ++s) th.x[s] = UPX_FMA_BUTTERFLY ? th.pre[s] : scale(th.pre[s], th.acc_c[s]);
+                            if constexpr (UPX_FMA_BUTTERFLY != 0) Dft<16>::first_sc(th.x, th.acc_c);
                         }
                         UPX_SCHED_FENCE();
-                        S::template pass_compute<0>(th, tw, sl);
+                        static_assert(PS::r[0] == 16, "pass 0 is one radix-16 butterfly per thread");
+                        if constexpr (UPX_FMA_BUTTERFLY != 0) Dft<16>::second_inplace(th.x);
+                        else S::template pass_compute<0>(th, tw, sl);
                         S::template pass_write<0>(th, lds_all + rho * BUF, sl);
                     });
                     ex.wg_barrier();
