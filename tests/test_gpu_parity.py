@@ -555,6 +555,47 @@ def test_band_limited_path_random_plans(ux, orc, monkeypatch):
     assert n_zoom >= 10   # the plans above are band-limited: most bands must have taken the path under test
 
 
+def test_band_limited_launch_geometries(ux, orc, monkeypatch):
+    """The band-limited synthesis' stream tables (every workgroup slot once, centre streams longer than the Ls/Rs ones, shorter
+    streams at the signal's edges), the analysis' pairs dealt by age and the priority turns are placement only: against the
+    oracle, and against the geometry of rounds 1-2 (UPX_ZOOM_ONCE=0) up to seam rounding; also with a scratch so small that
+    a call takes many launch pairs (every launch gets its own stream lists), and with the placement knobs at odd values."""
+    x = orc.synthetic_stereo(48000 * 25 + 321, 21)
+    edges = [0, 30, 120, 480, 1920, 7680]
+    ref_bands = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, 48000, max_block_size=8192)
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ref_bands)
+
+    def run(env):
+        for k in ("UPX_ZOOM_ONCE", "UPX_ZOOM_SCRATCH_MB", "UPX_ZOOM_C_COST", "UPX_ZOOM_EDGE_PERCENT", "UPX_ZOOM_A_AGE",
+                  "UPX_PRIO_YOUNG", "UPX_EDGE_PERCENT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        bands = gpu_chain(ux, edges, 48000, 8192, 32)
+        plan = ux.DevicePlan(bands)
+        assert "zoom" in plan.band_kernel_name(0) and "zoom" in plan.band_kernel_name(3)
+        out = plan.process(x)
+        again = plan.process(x)           # the cached tables of the second call
+        for u, v in zip(out, again):
+            assert np.array_equal(u, v)
+        plan.close()
+        return out
+
+    base = run({})
+    for g, r in zip(base, ref):
+        close(g, r)
+    for env in ({"UPX_ZOOM_ONCE": "0"},
+                {"UPX_ZOOM_SCRATCH_MB": "1"},                       # ~170 frames of P = 512 per launch pair
+                {"UPX_ZOOM_SCRATCH_MB": "1", "UPX_ZOOM_ONCE": "0"},
+                {"UPX_ZOOM_C_COST": "0.9", "UPX_ZOOM_EDGE_PERCENT": "50", "UPX_ZOOM_A_AGE": "30"},
+                {"UPX_PRIO_YOUNG": "0", "UPX_EDGE_PERCENT": "100", "UPX_ZOOM_EDGE_PERCENT": "100", "UPX_ZOOM_A_AGE": "0"}):
+        got = run(env)
+        for g, b, r in zip(got, base, ref):
+            close(g, r)
+            assert float(np.max(np.abs(g - b))) < 1e-6, env          # another cut: seam rounding only
+            assert rms(g.astype(np.float64) - b) < 1e-8, env
+
+
 def test_process_rank_single_gpu(ux, orc):
     """The per-rank entry of the multi-GPU path with world = 1 equals the plain call."""
     from upmix_amd import sharding
