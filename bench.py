@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 EDGES = [0, 30, 120, 480, 1920, 7680]
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 VALU_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: fp32 vector peak (SURVEY.md 8(d) secondary ceiling)
+TIMING_STRIDE = 4                # HIP events around the launches of every 4th step of the timed region
 ALGO_BYTES_IN, ALGO_BYTES_OUT = 8, 12   # per band 8 B stereo in + 12 B Ls/C/Rs out = 20 B per sample
 KERNEL_SOURCES = ["upmix_amd/csrc/upx_core.h", "upmix_amd/csrc/upx_zoom.h", "upmix_amd/csrc/upx_big.h",
                   "upmix_amd/csrc/upx_kernels.h", "upmix_amd/csrc/upx_lib.hip", "upmix_amd/csrc/upx_reg_big.hip",
@@ -377,12 +378,18 @@ def main():
     t0 = time.perf_counter()
     # HIP events on the plan's stream around every kernel launch group, kept per call by the library (64 calls) and
     # read after the loop: no synchronisation, and no reads, inside the timed region
-    for _ in range(args.steps):
+    # ... and only every TIMING_STRIDE-th step records them: the ten events of a C3 step cost 24 us of its 1.45 ms
+    # (scripts/timing_cost_check.py), which a production call does not pay
+    timed_steps = 0
+    for i in range(args.steps):
+        sampled = i % TIMING_STRIDE == 0
+        plan.pause_timing(not sampled)
+        timed_steps += sampled
         step()
     plan.sync()
     group.barrier()
     elapsed = group.allreduce_max([time.perf_counter() - t0])[0]    # the slowest rank's time
-    n_calls = min(64, args.steps * calls_per_step)          # the most recent timed process_device calls
+    n_calls = min(64, timed_steps * calls_per_step)         # the most recent timed process_device calls
     per_call = plan.band_times_calls_ms(n_calls) if n_calls else np.zeros((0, n_bands), np.float32)
     band_ms = per_call.mean(axis=0) if n_calls else np.zeros(n_bands)
     ana_sum, syn_sum = plan.band_phase_times_sum_ms(n_calls) if n_calls else (np.zeros(n_bands), np.zeros(n_bands))
@@ -455,6 +462,9 @@ def main():
             "preheat": {"untimed_steps": preheat_steps, "ms": args.preheat_ms,
                         "why": "an idle card reaches its running clocks after ~20 steps; run before the warm-up steps, "
                                "never inside the timed region (scripts/clock_ramp_check.py, DESIGN.md 5)"},
+            "kernel_timing": {"steps_with_events": timed_steps, "stride": TIMING_STRIDE,
+                              "why": "launches[].ms are HIP-event averages over every 4th step of the timed region: the "
+                                     "events themselves cost 1.7 % of a step (scripts/timing_cost_check.py)"},
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "weak",

@@ -325,6 +325,28 @@ def test_blocks_per_stream_only_moves_seam_rounding(ux, orc):
     plan.close()
 
 
+def test_timing_pause_keeps_recorded_calls(ux, orc):
+    """upx_plan_enable_timing 2 / 3 (resume / pause): a loop may time every n-th call; the ring keeps the timed ones only."""
+    x = orc.synthetic_stereo(150000, 12)
+    bands = gpu_chain(ux, [0, 300, 3000], 48000, 4096, 64)
+    plan = ux.DevicePlan(bands)
+    d_in = plan.alloc(x.nbytes)
+    d_out = [plan.alloc(len(x) * 4) for _ in range(3)]
+    plan.h2d(d_in, x)
+    plan.enable_timing(True)
+    for i in range(6):
+        plan.pause_timing(i % 3 != 0)       # calls 0 and 3 are timed
+        plan.process_device(d_in, len(x), len(x), d_out[0], d_out[1], d_out[2], len(x))
+    per_call = plan.band_times_calls_ms(2)
+    assert per_call.shape == (2, len(bands)) and np.all(per_call.sum(axis=1) > 0)
+    with pytest.raises(Exception):
+        plan.band_times_calls_ms(3)         # only two timed calls were recorded
+    plan.enable_timing(True)                # on again: forgets them
+    with pytest.raises(Exception):
+        plan.band_times_calls_ms(1)
+    plan.close()
+
+
 def test_device_helpers_absmax_scale(ux, orc):
     x = orc.synthetic_stereo(100001, 11)
     bands = gpu_chain(ux, [0, 300, 3000], 48000, 1024, 32)

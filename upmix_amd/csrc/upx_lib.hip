@@ -818,8 +818,8 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             const int groups = s.zoom_d / s.zoom->rg;
             const int res_s = zoom_resident(s);
             const long long tail = (long long)(s.k - 1) * s.hop;
-            // Launch pairs (analysis, synthesis) and the streams of each: `cut` = pair index where a launch ends; the
-            // stream tables hold the first frame of every Ls/Rs stream and of every centre stream, launch after launch.
+            // Launch pairs (analysis, synthesis) over consecutive runs of frame pairs (what the scratch holds), and the streams
+            // of each; the tables hold the first frame of every Ls/Rs stream and of every centre stream, launch after launch.
             struct Launch { long long pair0, pair_end; int s0_lr, ns_lr, s0_c, ns_c; bool once; };
             std::vector<Launch> launches;
             std::vector<int> tab_lr, tab_c;
@@ -1355,6 +1355,10 @@ int upx_process_tracks(upx_plan* p, int32_t n_tracks, const float* const* stereo
 
 int upx_plan_enable_timing(upx_plan* p, int enable) {
     if (!p) return fail(UPX_ERR_INVALID, "upx_plan_enable_timing: NULL plan");
+    if (enable == 2 || enable == 3) {   // resume / pause: the calls recorded so far stay (a loop that times every n-th call)
+        p->timing = enable == 2;
+        return UPX_OK;
+    }
     p->timing = enable != 0;
     p->timed_calls = 0;
     if (!p->timing) p->timed_once = false;

@@ -148,6 +148,10 @@ class DevicePlan:
     def enable_timing(self, on: bool = True) -> None:
         _lib.check(self._lib.upx_plan_enable_timing(self.handle, 1 if on else 0))
 
+    def pause_timing(self, paused: bool = True) -> None:
+        """Stop / resume recording events without forgetting the calls recorded so far (a loop that times every n-th call)."""
+        _lib.check(self._lib.upx_plan_enable_timing(self.handle, 3 if paused else 2))
+
     def band_times_ms(self) -> np.ndarray:
         ms = np.zeros(self.n_bands, dtype=np.float32)
         _lib.check(self._lib.upx_plan_band_times_ms(self.handle, _f32p(ms), self.n_bands))
