@@ -542,7 +542,8 @@ struct Dft<16> {
             v[k1] = y[0][k1]; v[k1 + 4] = y[1][k1]; v[k1 + 8] = y[2][k1]; v[k1 + 12] = y[3][k1];
         }
     }
-    // run_sc in two steps, in place: first_sc leaves y[b][k1] in v[4 k1 + b], second_inplace finishes
+    // the DFT of (s[0] v[0], ..., s[15] v[15]), s real, in two steps and in place: first_sc leaves y[b][k1] in v[4 k1 + b],
+    // second_inplace finishes
     static UPX_HD void first_sc(cf* v, const float* s) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) dft4_sc(v[b], v[4 + b], v[8 + b], v[12 + b], s[b], s[4 + b], s[8 + b], s[12 + b]);
@@ -552,16 +553,6 @@ struct Dft<16> {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             y[b][0] = v[b]; y[b][1] = v[4 + b]; y[b][2] = v[8 + b]; y[b][3] = v[12 + b];
-        }
-        second(v, y);
-    }
-    // the DFT of (s[0] v[0], ..., s[15] v[15]), s real
-    static UPX_HD void run_sc(cf* v, const float* s) {
-        cf y[4][4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            y[b][0] = v[b]; y[b][1] = v[4 + b]; y[b][2] = v[8 + b]; y[b][3] = v[12 + b];
-            dft4_sc(y[b][0], y[b][1], y[b][2], y[b][3], s[b], s[4 + b], s[8 + b], s[12 + b]);
         }
         second(v, y);
     }
@@ -587,8 +578,7 @@ struct Dft<16> {
         }
 #if UPX_FMA_BUTTERFLY
         second(v, y);
-        return;
-#endif
+#else
         const cf w1 = mk(kC16, -kS16), w3 = mk(kS16, -kC16);
         y[1][1] = cmul(y[1][1], w1);
         y[1][2] = mul_w8_1(y[1][2]);
@@ -604,6 +594,7 @@ struct Dft<16> {
             else dft4(y[0][k1], y[1][k1], y[2][k1], y[3][k1]);
             v[k1] = y[0][k1]; v[k1 + 4] = y[1][k1]; v[k1 + 8] = y[2][k1]; v[k1 + 12] = y[3][k1];
         }
+#endif
     }
     // inputs 4a + b with mask bit set may be non-zero, outputs k1 + 4 k2 with mask bit set are used
     static constexpr unsigned col4(unsigned m, int b) { return bit(m, b) | bit(m, 4 + b) << 1 | bit(m, 8 + b) << 2 | bit(m, 12 + b) << 3; }
@@ -1238,7 +1229,7 @@ UPX_HD void band_program(Ex& ex, const BandArgs& a, cf* lds_all, int wg_index) {
 #pragma unroll
             for (int s = 0; s < P; ++s) wa[s] = gat(w_a, (unsigned)lane, s * LANES);
         }
-        // (the window folded into pass 0's first butterflies - Dft<16>::run_sc, as the band-limited analysis does - made
+        // (the window folded into pass 0's first butterflies - Dft<16>::first_sc, as the band-limited analysis does - made
         // these kernels 0-2 % slower: not used here)
         if (hr.fast) {
 #pragma unroll
