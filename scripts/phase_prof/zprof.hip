@@ -93,7 +93,7 @@ int run(int log2n, int kernel, int period, int F, int frames) {
     CK(hipMalloc(&d_wa, N * 4)); CK(hipMalloc(&d_ws, N * 4)); CK(hipMalloc(&d_gain, gain.size() * 4));
     CK(hipMalloc(&d_tw, tw.size() * 8)); CK(hipMalloc(&d_ramp, ramp.size() * 8));
     CK(hipMalloc(&d_y, (size_t)frames * P * 12));
-    CK(hipMalloc(&d_seam, n_streams * 3 * (Z::K - 1) * hop * 4));   // [streams][2][tail] Ls/Rs, then [streams][tail] centre CK(hipMalloc(&d_buf, cap * 8));
+    CK(hipMalloc(&d_seam, n_streams * 3 * (Z::K - 1) * hop * 4)); /* [streams][2][tail] Ls/Rs, then [streams][tail] centre */ CK(hipMalloc(&d_buf, cap * 8));
     CK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_wa, wa.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_ws, ws.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_gain, gain.data(), gain.size() * 4, hipMemcpyHostToDevice));
