@@ -606,6 +606,20 @@ def test_band_limited_launch_geometries(ux, orc, monkeypatch):
     base = run({})
     for g, r in zip(base, ref):
         close(g, r)
+    # calls of alternating length back to back, no synchronisation in between: the stream tables follow in stream order
+    bands = gpu_chain(ux, edges, 48000, 8192, 32)
+    plan = ux.DevicePlan(bands)
+    n, short = len(x), len(x) - 123457
+    d_in = plan.alloc(x.nbytes)
+    d_out = [plan.alloc(n * 4) for _ in range(3)]
+    plan.h2d(d_in, x)
+    for t in (n, short, n, short, n):
+        plan.process_device(d_in, t, t, d_out[0], d_out[1], d_out[2], t)
+    for d, b in zip(d_out, base):
+        got = np.empty(n, dtype=np.float32)
+        plan.d2h(got, d)
+        assert np.array_equal(got, b)
+    plan.close()
     for env in ({"UPX_ZOOM_ONCE": "0"},
                 {"UPX_ZOOM_SCRATCH_MB": "1"},                       # ~170 frames of P = 512 per launch pair
                 {"UPX_ZOOM_SCRATCH_MB": "1", "UPX_ZOOM_ONCE": "0"},

@@ -899,9 +899,10 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                 s.h_m0_sent.clear();
             }
             if (s.h_m0 != s.h_m0_sent) {
-                HIP_TRY(hipStreamSynchronize(p->stream));   // (the previous call's kernels read the old table)
+                // in stream order behind the previous call's kernels, which read the old table; the source is pageable, so the
+                // call returns when it has been read (tracks of unequal length change the geometry call after call: no
+                // synchronisation here, the uploads and downloads of the neighbouring tracks keep running)
                 HIP_TRY(hipMemcpyAsync(s.d_m0, s.h_m0.data(), s.h_m0.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
-                HIP_TRY(hipStreamSynchronize(p->stream));   // h_m0 may change before an asynchronous copy has read it
                 s.h_m0_sent = s.h_m0;
             }
             const size_t seam_need = (size_t)(2 * n_lr_total + n_c_total) * tail;
