@@ -225,6 +225,10 @@ void upx_comm_destroy(upx_comm* comm);
  * own_len == 0 ranks are not supported.
  */
 int upx_comm_seam_exchange(upx_comm* comm, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill);
+/* Samples of the predecessor's spill that upx_comm_seam_exchange adds onto the head of `rank`: `spill`, except on the
+   LAST rank, whose planes may end at own_len < spill (sharding.ShardGeometry.plan only keeps shards with a successor
+   at least `spill` long; the rest of the spill lies past the signal's end); 0 for rank 0.  Pure arithmetic, no GPU. */
+int64_t upx_comm_seam_add_len(int rank, int n_ranks, int64_t own_len, int64_t spill);
 /* Test hook: run the same pack -> ncclAllReduce -> add sequence with a seam of n_rows rows, packing this rank's
    spill into row my_row and adding that same row back onto its own head (any communicator size, e.g. 1 rank). */
 int upx_comm_seam_selftest(upx_comm* comm, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill,

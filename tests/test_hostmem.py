@@ -99,3 +99,32 @@ def test_empty_gives_shaped_typed_arrays(monkeypatch):
     x[:] = 1.5
     y = hostmem.empty(12, np.int16, None)
     assert y.shape == (12,) and float(x.sum()) == 3000.0
+
+
+def test_a_result_that_outlives_every_plan_is_unpinned_when_it_dies(monkeypatch):
+    """Round-3 advisor finding: blocks still leased when the last plan closed stayed page-locked for good.  After trim()
+    (= the process' last plan closed) a dying array frees its block at once; a new take() (= a new plan) resumes pooling."""
+    pool, fake = make_pool(monkeypatch, 64 << 20)
+    kept = pool.take(1000, None)
+    idle = pool.take(1000, None)
+    del idle
+    gc.collect()
+    pool.trim(None)                                   # last plan closes: the idle block goes, `kept` is still leased
+    assert fake.frees == 1 and pool._held == hostmem._GRANULE and not pool.plans_live
+    del kept
+    gc.collect()
+    assert fake.frees == 2 and pool._held == 0 and not fake.bufs and not pool._returned
+    again = pool.take(10, None)                       # a new plan: pooling as before
+    assert pool.plans_live and fake.allocs == 3
+    del again
+    gc.collect()
+    assert fake.frees == 2 and len(pool._returned) == 1
+
+
+def test_default_limit_scales_with_ram_and_ranks(tmp_path):
+    info = tmp_path / "meminfo"
+    info.write_text("MemTotal:       134217728 kB\nMemFree: 1 kB\n")          # 128 GiB
+    assert hostmem.default_limit({}, str(info)) == 8192 << 20                  # one rank: the 8 GiB cap
+    assert hostmem.default_limit({"WORLD_SIZE": "8"}, str(info)) == 4096 << 20   # eight ranks: 128 / 4 / 8 = 4 GiB each
+    assert hostmem.default_limit({"WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "2"}, str(info)) == 8192 << 20
+    assert hostmem.default_limit({}, str(tmp_path / "absent")) == 8192 << 20

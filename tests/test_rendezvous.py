@@ -141,3 +141,36 @@ def test_busy_port_is_stepped_over():
     stop.set()
     foreign.close()
     assert got == [(0, 1.0), (1, 1.0)], got
+
+
+@pytest.mark.timeout(60)
+def test_silent_and_foreign_connections_do_not_capture_a_slot():
+    """Round-3 advisor finding: a connection that never says hello held the accept loop for the whole timeout, and a rank
+    of ANOTHER job of the same world size was accepted.  Now: the hello carries the job token, and a silent connection
+    is dropped after the short hello timeout."""
+    import socket
+    import threading
+    import time
+    port = free_port()
+    result = {}
+
+    def rank0():
+        with rendezvous.Rendezvous(0, 2, "127.0.0.1", port, timeout=30, token=b"job-A...") as g:
+            result["parts"] = g.allgather_bytes(b"zero")
+
+    old = rendezvous._HELLO_TIMEOUT
+    rendezvous._HELLO_TIMEOUT = 0.5
+    try:
+        t = threading.Thread(target=rank0)
+        t.start()
+        time.sleep(0.2)
+        silent = socket.create_connection(("127.0.0.1", port))             # a port probe: connects, says nothing
+        with pytest.raises(rendezvous.RendezvousError):                   # a rank of another job: refused
+            rendezvous.Rendezvous(1, 2, "127.0.0.1", port, timeout=1.5, token=b"job-B...")
+        with rendezvous.Rendezvous(1, 2, "127.0.0.1", port, timeout=20, token=b"job-A...") as g:
+            assert g.allgather_bytes(b"one") == [b"zero", b"one"]
+        t.join(20)
+        silent.close()
+        assert result["parts"] == [b"zero", b"one"]
+    finally:
+        rendezvous._HELLO_TIMEOUT = old

@@ -116,6 +116,7 @@ def main(argv=None) -> int:
                                 threshold_factor=a.threshold_factor, xo_fraction=a.xo_fraction, device=device,
                                 verbose=rank == 0)
             plan = DevicePlan(bands, device)
+            ahead = None
             try:
                 def on_device(i):
                     m = metas[i]
@@ -162,6 +163,15 @@ def main(argv=None) -> int:
                     print(f"[rank {rank}] Wrote => {out}")
                 pending.clear()
             finally:
+                # nothing may still be using the plan when it is destroyed (round-3 advisor finding: on the error path the
+                # reader thread could be inside fetch() -> plan.host_empty -> upx_host_alloc(plan)): wait for the read
+                # ahead and for the writer jobs, whatever they end with, before the plan goes
+                for fut in ([ahead] if ahead is not None else []) + [f for f, _ in pending]:
+                    try:
+                        fut.result()
+                    except Exception:   # noqa: BLE001 - the exception that brought us here is the one that propagates
+                        pass
+                pending.clear()
                 plan.close()
     print(f"[rank {rank}] Done ({len(mine)} of {len(paths)} tracks).")
     return 0

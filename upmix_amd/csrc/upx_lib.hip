@@ -719,8 +719,8 @@ int upx_host_alloc(upx_plan* p, void** ptr, size_t bytes) {
     return UPX_OK;
 }
 int upx_host_free(upx_plan* p, void* ptr) {
-    if (!p) return fail(UPX_ERR_INVALID, "upx_host_free: NULL plan");
-    HIP_TRY(hipSetDevice(p->device));
+    // plan == NULL: a block that outlived every plan of the process (hostmem.py); page-locked memory is not tied to a device
+    if (p) HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipHostFree(ptr));
     return UPX_OK;
 }
@@ -1718,8 +1718,10 @@ void upx_comm_destroy(upx_comm* c) {
 
 namespace {
 // pack my spill into row `my_row` of seam[n_rows][3][spill], all-reduce, add row `add_row` onto my head
+// `add_len` <= spill: samples of the predecessor's spill that land inside this rank's planes (the LAST shard's planes end at
+// own_len, which ShardGeometry.plan allows to be shorter than the spill; what lies beyond is past the signal's end)
 int seam_exchange_impl(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill, int n_rows,
-                       int my_row, bool pack, int add_row) {
+                       int my_row, bool pack, int add_row, int64_t add_len) {
     upx_plan* p = c->plan;
     HIP_TRY(hipSetDevice(p->device));
     const long long row = 3 * (long long)spill, total = row * n_rows;
@@ -1734,29 +1736,36 @@ int seam_exchange_impl(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t 
         hipLaunchKernelGGL(upx_seam_pack_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream,
                            c->d_seam + row * my_row, d_c, d_l, d_r, (long long)own_len, (long long)spill);
     NCCL_TRY(g_rccl.AllReduce(c->d_seam, c->d_seam, (size_t)total, ncclFloat32, ncclSum, c->comm, p->stream));
-    if (add_row >= 0) {
+    if (add_row >= 0 && add_len > 0) {
         const float* prev = c->d_seam + row * add_row;
-        hipLaunchKernelGGL(upx_seam_add_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream, d_c, d_l, d_r, prev,
-                           prev + spill, prev + 2 * spill, (long long)spill);
+        hipLaunchKernelGGL(upx_seam_add_kernel, dim3(grid_for(add_len)), dim3(256), 0, p->stream, d_c, d_l, d_r, prev,
+                           prev + spill, prev + 2 * spill, (long long)add_len);
     }
     HIP_TRY(hipGetLastError());
     return UPX_OK;
 }
 }   // namespace
 
+int64_t upx_comm_seam_add_len(int rank, int n_ranks, int64_t own_len, int64_t spill) {
+    if (rank <= 0 || rank >= n_ranks || own_len <= 0 || spill <= 0) return 0;
+    return rank + 1 == n_ranks && own_len < spill ? own_len : spill;
+}
+
 int upx_comm_seam_exchange(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill) {
     if (!c || !d_c || !d_l || !d_r || own_len <= 0 || spill < 0) return fail(UPX_ERR_INVALID, "upx_comm_seam_exchange: bad argument");
     if (spill == 0 || c->n_ranks == 1) return UPX_OK;
-    // the last rank's spill lies beyond the signal; rank 0 has no predecessor
-    return seam_exchange_impl(c, d_c, d_l, d_r, own_len, spill, c->n_ranks, c->rank, c->rank + 1 < c->n_ranks,
-                              c->rank > 0 ? c->rank - 1 : -1);
+    // the last rank's spill lies beyond the signal; rank 0 has no predecessor.  A rank with a successor holds planes of
+    // own_len + spill samples (>= spill); the last rank's planes may end at own_len < spill (upx_wav_shard_begin)
+    const bool last = c->rank + 1 == c->n_ranks;
+    return seam_exchange_impl(c, d_c, d_l, d_r, own_len, spill, c->n_ranks, c->rank, !last, c->rank > 0 ? c->rank - 1 : -1,
+                              upx_comm_seam_add_len(c->rank, c->n_ranks, own_len, spill));
 }
 
 int upx_comm_seam_selftest(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill, int n_rows,
                            int my_row) {
     if (!c || !d_c || !d_l || !d_r || own_len <= 0 || spill <= 0 || n_rows < 1 || my_row < 0 || my_row >= n_rows)
         return fail(UPX_ERR_INVALID, "upx_comm_seam_selftest: bad argument");
-    return seam_exchange_impl(c, d_c, d_l, d_r, own_len, spill, n_rows, my_row, true, my_row);
+    return seam_exchange_impl(c, d_c, d_l, d_r, own_len, spill, n_rows, my_row, true, my_row, spill);
 }
 
 int upx_seam_add_local(upx_plan* p, const float* pc, const float* pl, const float* pr, int64_t prev_own_len,

@@ -16,6 +16,7 @@ from __future__ import annotations
 import collections
 import ctypes as C
 import os
+import sys
 import threading
 from typing import Dict, List
 
@@ -52,6 +53,7 @@ class PinnedPool:
         self._lock = threading.Lock()
         self._plan_handle = None  # any live upx_plan of the process (allocation needs a device context)
         self.closed = False
+        self.plans_live = True    # False between the close of the process' last plan and the creation of the next one
 
     def take(self, nbytes: int, plan_handle) -> np.ndarray:
         """uint8[nbytes] in page-locked memory; plain pageable memory if the pool is at its limit or pinning fails."""
@@ -80,9 +82,19 @@ class PinnedPool:
                 ptr = p.value
                 self._held += cap
             self._plan_handle = plan_handle
+            self.plans_live = True
         return np.asarray(_Lease(self, ptr, cap, nbytes))
 
     def _give_back(self, ptr: int, cap: int) -> None:
+        if not self.plans_live and not self.closed and not sys.is_finalizing():
+            # a result that outlived every plan: nothing will ask the pool for memory again soon, so the block is
+            # unpinned now instead of staying page-locked for the rest of the process (upx_host_free takes no plan then)
+            try:
+                if _lib.load().upx_host_free(None, C.c_void_p(ptr)) == _lib.UPX_OK:
+                    self._held -= cap      # (int update under the GIL; take() re-reads it under its lock)
+                    return
+            except Exception:              # interpreter teardown, library gone: the runtime frees it at unload
+                pass
         self._returned.append((ptr, cap))   # (a closed pool keeps them: the runtime frees the blocks at unload)
 
     def _collect(self) -> None:
@@ -103,18 +115,43 @@ class PinnedPool:
                 while stack:
                     lib.upx_host_free(plan_handle, C.c_void_p(stack.pop()))
                     self._held -= cap
+            self.plans_live = False     # (DevicePlan.close calls this for the process' last plan)
 
     def close(self) -> None:
         with self._lock:
             self.closed = True
 
 
-def _limit_from_env() -> int:
-    """UPX_PINNED_POOL_MB (read once): cap of the pool, default 8 GiB, 0 disables it."""
+def default_limit(env=os.environ, meminfo: str = "/proc/meminfo") -> int:
+    """
+    Cap of the pool when UPX_PINNED_POOL_MB is not set: 8 GiB, but never more than a quarter of the host's RAM divided
+    by the ranks that share the host (LOCAL_WORLD_SIZE, else WORLD_SIZE: one process per GPU, each with its own pool) -
+    eight ranks on a 2 TiB node may pin 64 GiB together, eight ranks on a 128 GiB node 4 GiB each.
+    """
+    cap = 8192 << 20
     try:
-        return int(os.environ.get("UPX_PINNED_POOL_MB", "8192")) << 20
+        ranks = max(1, int(env.get("LOCAL_WORLD_SIZE") or env.get("WORLD_SIZE") or 1))
+        with open(meminfo) as fh:
+            for line in fh:
+                if line.startswith("MemTotal:"):
+                    total = int(line.split()[1]) << 10
+                    cap = min(cap, total // 4 // ranks)
+                    break
+    except (OSError, ValueError):
+        pass
+    return cap
+
+
+def _limit_from_env() -> int:
+    """UPX_PINNED_POOL_MB (read once): cap of the pool in MiB, 0 disables it (every result is a plain pageable NumPy
+    array, as the reference returns them); unset: default_limit()."""
+    v = os.environ.get("UPX_PINNED_POOL_MB")
+    if v is None:
+        return default_limit()
+    try:
+        return int(v) << 20
     except ValueError:
-        return 8192 << 20
+        return default_limit()
 
 
 POOL = PinnedPool(_limit_from_env())

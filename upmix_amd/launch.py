@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import secrets
 import signal
 import socket
 import subprocess
@@ -30,20 +31,57 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def run(nproc: int, command: List[str], master_addr: str = "127.0.0.1", master_port: int = 0, env=None) -> int:
-    """Start `command` nproc times (rank r gets RANK = LOCAL_RANK = r); -> 0, or the first non-zero exit code."""
+class _Terminated(Exception):
+    """SIGTERM / SIGHUP reached the launcher: raised into the wait loop so that its `finally` ends the ranks."""
+
+    def __init__(self, signum):
+        super().__init__(signum)
+        self.signum = signum
+
+
+def exit_code(code: int) -> int:
+    """A child killed by signal N has return code -N; the launcher exits 128 + N, like a shell."""
+    return 128 - code if code < 0 else code
+
+
+def run(nproc: int, command: List[str], master_addr: str = "127.0.0.1", master_port: int = 0, env=None,
+        capture_rank0: bool = False):
+    """
+    Start `command` nproc times (rank r gets RANK = LOCAL_RANK = r); -> 0, or the first non-zero exit code (128 + N for a
+    rank killed by signal N).  A SIGTERM or SIGHUP to the launcher (scheduler pre-emption, `timeout`) ends the ranks too.
+    Every job gets its own UPX_RDZV_TOKEN (rendezvous.job_token).  `capture_rank0`: -> (code, rank 0's stdout as text).
+    """
     if nproc < 1:
         raise ValueError("nproc must be >= 1")
     port = master_port or free_port()
+    token = secrets.token_hex(8)
     procs = []
-    for rank in range(nproc):
-        e = dict(os.environ if env is None else env)
-        e.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(nproc), MASTER_ADDR=master_addr,
-                 MASTER_PORT=str(port))
-        e.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # no launcher-side store on MASTER_PORT here
-        procs.append(subprocess.Popen(command, env=e))
     rc = 0
+    out0 = ""
+    old = {}
+
+    def on_signal(signum, _frame):
+        raise _Terminated(signum)
+
     try:
+        for sig in (signal.SIGTERM, signal.SIGHUP):
+            try:
+                old[sig] = signal.signal(sig, on_signal)
+            except ValueError:                            # not the main thread: the caller keeps its own handlers
+                pass
+        for rank in range(nproc):
+            e = dict(os.environ if env is None else env)
+            e.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(nproc), MASTER_ADDR=master_addr,
+                     MASTER_PORT=str(port), UPX_RDZV_TOKEN=token)
+            e.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # no launcher-side store on MASTER_PORT here
+            procs.append(subprocess.Popen(command, env=e,
+                                          stdout=subprocess.PIPE if capture_rank0 and rank == 0 else None, text=True))
+        reader = None
+        if capture_rank0:
+            import threading
+            chunks = []
+            reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+            reader.start()                                # (the wait loop below keeps watching the other ranks)
         alive = list(procs)
         while alive and rc == 0:
             time.sleep(0.05)
@@ -53,8 +91,15 @@ def run(nproc: int, command: List[str], master_addr: str = "127.0.0.1", master_p
                     continue
                 alive.remove(p)
                 if code != 0:
-                    rc = code
+                    rc = exit_code(code)
+        if reader is not None and rc == 0:
+            reader.join()
+            out0 = "".join(chunks)
+    except _Terminated as t:
+        rc = 128 + t.signum
     finally:
+        for sig, handler in old.items():
+            signal.signal(sig, handler)
         for p in procs:                                   # a failed rank takes the others down (exact PIDs only)
             if p.poll() is None:
                 p.send_signal(signal.SIGTERM)
@@ -65,7 +110,7 @@ def run(nproc: int, command: List[str], master_addr: str = "127.0.0.1", master_p
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
-    return rc
+    return (rc, out0) if capture_rank0 else rc
 
 
 def main(argv=None) -> int:

@@ -11,12 +11,15 @@ Address: the launcher's MASTER_ADDR / MASTER_PORT (torch.distributed.run, or any
 WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  torch.distributed.run keeps its own store on MASTER_PORT (it says so with
 TORCHELASTIC_USE_AGENT_STORE=True), so the star then starts at MASTER_PORT + 1.  Should that port be taken, rank 0
 listens on the next free one of the following seven and the other ranks find it by trying the same eight in turn (the
-hello carries a magic word, the rank and the world size, so a foreign service is recognised and skipped).
-UPX_RDZV_PORT pins one port.
+hello carries a magic word, the rank, the world size and a hash of the job token - UPX_RDZV_TOKEN, which upmix_amd.launch
+generates per job, else TORCHELASTIC_RUN_ID - so a foreign service, and a rank of ANOTHER job of the same size on the
+same port, is recognised and skipped; an accepted connection has 5 s to say hello, so a silent one - a port probe -
+cannot hold up the accept loop).  UPX_RDZV_PORT pins one port.
 The reference has no counterpart: its only parallelism is a thread pool (center_extraction.py:499-501).
 """
 from __future__ import annotations
 
+import hashlib
 import math
 import os
 import socket
@@ -24,8 +27,15 @@ import struct
 import time
 from typing import List, Optional, Sequence
 
-_MAGIC = b"UPXRDZV1"
+_MAGIC = b"UPXRDZV2"
 _OK, _FAIL = 0, 1
+_HELLO_TIMEOUT = 5.0      # an accepted connection that says nothing for this long is dropped (the ranks retry)
+
+
+def job_token(env=os.environ) -> bytes:
+    """8 bytes that identify the job: two jobs of the same world size on one MASTER_PORT must not capture each other's ranks."""
+    tok = env.get("UPX_RDZV_TOKEN") or env.get("TORCHELASTIC_RUN_ID") or ""
+    return hashlib.sha256(tok.encode("utf-8", "replace")).digest()[:8]
 
 
 class RendezvousError(RuntimeError):
@@ -68,8 +78,10 @@ class Rendezvous:
     """
 
     def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29500, timeout: float = 600.0,
-                 n_ports: int = 1):
-        """`port` .. `port + n_ports - 1`: rank 0 listens on the first one it can bind, the others try them in turn."""
+                 n_ports: int = 1, token: Optional[bytes] = None):
+        """`port` .. `port + n_ports - 1`: rank 0 listens on the first one it can bind, the others try them in turn.
+        `token`: 8 bytes shared by the ranks of one job (default: job_token() of the environment)."""
+        token = (job_token() if token is None else bytes(token)[:8]).ljust(8, b"\0")
         if world < 1 or not 0 <= rank < world:
             raise ValueError(f"rank {rank} of {world}")
         self.rank, self.world = int(rank), int(world)
@@ -104,18 +116,24 @@ class Rendezvous:
                 except socket.timeout as exc:
                     self.close()
                     raise RendezvousError(f"{missing} of {world - 1} ranks did not connect within {timeout:g} s") from exc
-                conn.settimeout(timeout)
+                conn.settimeout(min(timeout, _HELLO_TIMEOUT))
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 try:
-                    hello = _recv_exact(conn, len(_MAGIC) + 8)
-                    magic, r, w = hello[:len(_MAGIC)], *struct.unpack("<ii", hello[len(_MAGIC):])
+                    hello = _recv_exact(conn, len(_MAGIC) + 16)
+                    magic, r, w = hello[:len(_MAGIC)], *struct.unpack("<ii", hello[len(_MAGIC):len(_MAGIC) + 8])
+                    theirs = hello[len(_MAGIC) + 8:]
                 except (RendezvousError, OSError, struct.error):
+                    conn.close()                    # silent or foreign: the accept loop moves on
+                    continue
+                if magic != _MAGIC or w != world or theirs != token or not 0 < r < world or self._peers[r] is not None:
+                    conn.close()                    # not one of ours (or a rank of another job: it keeps trying its own ports)
+                    continue
+                try:
+                    conn.sendall(_MAGIC)
+                except OSError:
                     conn.close()
                     continue
-                if magic != _MAGIC or w != world or not 0 < r < world or self._peers[r] is not None:
-                    conn.close()                    # not one of ours (or a stale rank of another job)
-                    continue
-                conn.sendall(_MAGIC)
+                conn.settimeout(timeout)
                 self._peers[r] = conn
                 missing -= 1
         else:
@@ -129,7 +147,7 @@ class Rendezvous:
                     s = socket.create_connection((addr, cand), timeout=min(5.0, max(0.1, deadline - time.monotonic())))
                     s.settimeout(min(timeout, 10.0))          # a foreign service that never answers is given up on
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    s.sendall(_MAGIC + struct.pack("<ii", rank, world))
+                    s.sendall(_MAGIC + struct.pack("<ii", rank, world) + token)
                     if _recv_exact(s, len(_MAGIC)) != _MAGIC:
                         raise RendezvousError("unexpected reply")
                     s.settimeout(timeout)
