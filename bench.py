@@ -2,12 +2,21 @@
 """
 bench.py - headline benchmark: stereo Msamples/s upmixed (6 bands, STFT <= 8192).
 
-    python bench.py --gpus 1 --steps K --warmup W [--workload c3|default|c4share|batch]
+    python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|default|c4share|batch]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+N > 1 works both ways: under a launcher that exports RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run,
+upmix_amd.launch, srun ...) this process is one rank; WITHOUT one (the bare `python bench.py --gpus N`) it is only a
+parent that starts the N ranks itself through upmix_amd.launch.run - fresh child processes, never a re-exec, and the
+parent makes no GPU call - and exits with their code; rank 0 prints the JSON line on the stdout they share.
+
 A "step" is one pass of the hot path over synthetic stereo already resident in HBM.  Workloads:
 
+  c1       BASELINE configs[0] (the reference's own CPU-runnable case): 10 s of 48 kHz stereo, ONE band 0-24 kHz,
+           STFT 2048, 75 % overlap; its cpu_baseline runs the WHOLE config on the host.
+  c2       BASELINE configs[1]: 60 s of 48 kHz stereo, 3 bands (crossovers 300 / 3000 Hz), threshold_factor 64,
+           max STFT 4096 -> STFT [4096, 4096, 1024].
   c3       (default; the line the driver records) BASELINE.json configs[2]: 10 min of 48 kHz stereo, 6 bands, edges
            0/30/120/480/1920/7680 Hz, STFT [8192,8192,8192,4096,1024,256], Blackman-Harris, 75 % overlap, raised-cosine
            crossovers.  N > 1 ranks: N x 10 min, time-sharded on the hop_max grid (one shard per GPU, weak scaling),
@@ -49,13 +58,46 @@ KERNEL_SOURCES = ["upmix_amd/csrc/upx_core.h", "upmix_amd/csrc/upx_zoom.h", "upm
                   "upmix_amd/csrc/upx_reg_zoom1024.hip"]
 
 WORKLOADS = {
-    #          sr     seconds  max_stft  BASELINE config
-    "c3":      (48000, 600,    8192,     "BASELINE configs[2]"),
-    "default": (48000, 600,    65536,    "configs[2] signal, reference default plan (max STFT 65536)"),
-    "c4share": (96000, 900,    8192,     "one GPU's share of BASELINE configs[3] (2 h at 96 kHz over 8 GPUs)"),
-    "batch":   (48000, 300,    8192,     "BASELINE configs[4] (8 tracks of 5 min per GPU)"),
+    #          sr     seconds  max_stft  BASELINE config                                       band edges (None: the six-band EDGES), threshold_factor, seed
+    "c1":      (48000, 10,     2048,     "BASELINE configs[0]",                                 "single", 32, 0),
+    "c2":      (48000, 60,     4096,     "BASELINE configs[1]",                                 [0, 300, 3000], 64, 1),
+    "c3":      (48000, 600,    8192,     "BASELINE configs[2]",                                 None, 32, 2),
+    "default": (48000, 600,    65536,    "configs[2] signal, reference default plan (max STFT 65536)", None, 32, 2),
+    "c4share": (96000, 900,    8192,     "one GPU's share of BASELINE configs[3] (2 h at 96 kHz over 8 GPUs)", None, 32, 2),
+    "batch":   (48000, 300,    8192,     "BASELINE configs[4] (8 tracks of 5 min per GPU)",    None, 32, 2),
 }
 TRACKS_PER_GPU = 8
+
+
+def workload_bands(workload, make_single, chain):
+    """
+    The band list of a workload through the caller's constructors (upmix_amd's or the oracle's - the same call shapes):
+    `make_single(block, overlap, f_lo, f_hi, sr, xover_mode, width_lo, width_hi)` for configs[0]'s one full band
+    (center_extraction.py:217-271 called directly, as SURVEY.md 8 C1 states it: STFT 2048, 0-24 kHz, no fade at 0 Hz,
+    none reached at Nyquist), `chain(edges, sr, max_stft, threshold_factor)` = chain_bands (:518-580) for the others.
+    """
+    sr, _seconds, max_stft, _cfg, edges, factor, _seed = WORKLOADS[workload]
+    if edges == "single":
+        return [make_single(max_stft, 0.75, 0.0, sr / 2.0, sr, "raised_cosine", 0.0, 0.25 * sr / 2.0)]
+    return chain(EDGES if edges is None else edges, sr, max_stft, factor)
+
+
+def host_description():
+    """What the CPU line ran on: logical CPUs visible, the model string of /proc/cpuinfo, NumPy's version."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count()
+    return {"host_cpus": os.cpu_count(), "usable_cpus": usable, "cpu_model": model, "numpy": np.__version__}
 
 
 def synth(total, seed):
@@ -76,40 +118,56 @@ def kernel_sources_sha():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(sr, max_stft, target_seconds=15.0):
+def cpu_baseline(workload, target_seconds=15.0):
     """
     The oracle in the reference's scheduling shape (ThreadPoolExecutor(), one task per band, sequential
-    frame loop per band) on a bounded prefix of the same workload: a 10 s calibration slice sizes the
-    timed sample so that it costs about `target_seconds` of CPU wall time.
+    frame loop per band: center_extraction.py:499-501 -> :449-460) on a bounded sample of the same workload: a
+    calibration slice (10 s of audio, or the whole workload if that is shorter) sizes the timed sample so that it costs
+    about `target_seconds` of CPU wall time, capped at the workload's own length (configs[0] runs whole).
     """
     from oracle import upmix_oracle as orc
-    bands = orc.plan_bands(EDGES, 0.75, orc.win_blackman_harris, sr, max_block_size=max_stft)
+    sr, seconds, _max_stft, _cfg, _edges, _factor, seed = WORKLOADS[workload]
+    bands = workload_bands(workload, orc.Band,
+                           lambda e, sr_, m, f: orc.plan_bands(e, 0.75, orc.win_blackman_harris, sr_, max_block_size=m,
+                                                               threshold_factor=f))
 
-    def run(seconds):
-        total = int(sr * seconds)
-        x = synth(total, 2).astype(np.float64)
+    def run(secs):
+        total = int(sr * secs)
+        x = synth(total, seed).astype(np.float64)
         t0 = time.perf_counter()
         orc.extract_multi_band_threadpool(x[:, 0], x[:, 1], bands)
         return total, time.perf_counter() - t0
 
-    total, dt = run(10.0)
-    sample_seconds = float(min(600, max(10.0, 10.0 * target_seconds / max(dt, 1e-3))))
-    if sample_seconds > 10.0:
+    calib = float(min(10.0, seconds))
+    total, dt = run(calib)
+    sample_seconds = float(min(seconds, max(calib, calib * target_seconds / max(dt, 1e-3))))
+    if sample_seconds > calib:
         total, dt = run(sample_seconds)
     else:
-        sample_seconds = 10.0
+        sample_seconds = calib
     # the same frame loops one band after the other (no thread pool): SURVEY 8(d) asks for both
-    xs = synth(int(sr * 10.0), 2).astype(np.float64)
+    xs = synth(int(sr * calib), seed).astype(np.float64)
     t0 = time.perf_counter()
     orc.extract_multi_band(xs[:, 0], xs[:, 1], bands, per_band=orc.band_process_streaming)
     serial = len(xs) / (time.perf_counter() - t0) / 1e6
-    return {
-        "value": round(total / dt / 1e6, 4), "unit": "Msamples/s", "cores": len(bands), "kind": "port",
+    # ThreadPoolExecutor() defaults to min(32, cpus + 4) workers (the reference's own call); one task per band
+    host = host_description()
+    threads = min(len(bands), min(32, (os.cpu_count() or 1) + 4))
+    whole = sample_seconds >= seconds
+    out = {
+        "value": round(total / dt / 1e6, 4), "unit": "Msamples/s",
+        "cores": threads, "threads_used": threads,
+        "cores_note": "threads that ran the frame loops: one task per band in the reference's ThreadPoolExecutor(), i.e. "
+                      "the band count (the GIL serialises most of it); the host's CPU count is host_cpus",
+        "kind": "port",
         "bands_serial_value": round(serial, 4),
-        "sample": f"first {sample_seconds:g} s of the same workload (seed 2), oracle/upmix_oracle.py "
-                  f"extract_multi_band_threadpool: ThreadPoolExecutor(), one task per band (={len(bands)} threads), "
-                  f"float64 numpy.fft, {os.cpu_count()} host cpus visible, {dt:.1f} s wall",
+        "sample": (f"the WHOLE workload ({sample_seconds:g} s of audio, seed {seed})" if whole else
+                   f"first {sample_seconds:g} s of the same workload (seed {seed})") +
+                  f", oracle/upmix_oracle.py extract_multi_band_threadpool: ThreadPoolExecutor(), one task per band "
+                  f"(= {threads} threads), float64 numpy.fft, {dt:.1f} s wall",
     }
+    out.update(host)
+    return out
 
 
 def executed_flops_per_sample(kernel_name, n, k, n_bands_in_launch, phase):
@@ -134,6 +192,7 @@ def canonical_kernel_name(name):
     """One spelling for a kernel whether the library's table or rocprofv3 names it: no blanks ("> >"), no default
     template arguments (rocprofv3 prints upx::Live<0, 1048576> for the general flavour), no namespace of the symbol."""
     name = name.replace(" ", "").replace(",upx::Live<0,1048576>", "")
+    name = re.sub(r"^(upxk::)?(upx_band_kernel<.*),true>$", r"\1\2>", name)     # MERGED = true is the template's default too
     return re.sub(r"^(void)?(\(anonymousnamespace\)::|upxk::)?", "", name)
 
 
@@ -160,11 +219,11 @@ def load_pmc_traffic(kernel_tag, workload="c3"):
     return v, (None if v is not None else "kernel not in profiles/pmc_traffic.json")
 
 
-def e2e_rates(ux, plan, bands, sr, nominal):
+def e2e_rates(ux, plan, bands, sr, nominal, seed=2):
     """PCIe-inclusive rates of the host-buffer entry points on this workload's signal (never `value`)."""
     from upmix_amd import wav as _wav  # noqa: F401
     out = {}
-    x = synth(nominal, 2)
+    x = synth(nominal, seed)
 
     def timed(fn, reps=3):
         best = None
@@ -259,12 +318,21 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive side measurements")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # The bare command: nobody started the ranks, so this process does - N fresh children of itself with RANK /
+        # LOCAL_RANK / WORLD_SIZE / MASTER_* set (upmix_amd.launch.run: no re-exec, and nothing in this parent has
+        # touched the GPU runtime), rank 0 among them prints the JSON line on the shared stdout.
+        from upmix_amd import launch
+        sys.stdout.flush()
+        return launch.run(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        # a launcher's world size wins over the flag (the driver passes both, equal)
+        print(f"[bench] WARNING: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
         args.gpus = world
 
     from upmix_amd.rendezvous import Rendezvous
@@ -281,13 +349,17 @@ def main():
               file=sys.stderr)
     local_rank = local_rank % n_dev
 
-    sr, seconds, max_stft, cfg_name = WORKLOADS[args.workload]
+    sr, seconds, max_stft, cfg_name, wl_edges, wl_factor, seed = WORKLOADS[args.workload]
     if args.seconds is not None:
         seconds = args.seconds
     nominal = int(sr * seconds)
     batch = args.workload == "batch"
-    bands = ux.chain_bands(EDGES, 0.75, ux.make_blackman_harris, sr, max_block_size=max_stft, verbose=False,
-                           device=local_rank)
+    bands = workload_bands(
+        args.workload,
+        lambda n, ov, lo, hi, sr_, mode, wlo, whi: ux.MultiBandExtractorAccu(n, ov, ux.make_blackman_harris, lo, hi, sr_,
+                                                                             mode, wlo, whi, device=local_rank),
+        lambda e, sr_, m, f: ux.chain_bands(e, 0.75, ux.make_blackman_harris, sr_, max_block_size=m, threshold_factor=f,
+                                            verbose=False, device=local_rank))
     plan = ux.DevicePlan(bands, device=local_rank)
     n_bands = len(bands)
 
@@ -317,9 +389,9 @@ def main():
         own, t_in, t_out = shard.own_len, shard.t_in, shard.t_out
         spill = geo.spill if world > 1 else 0
         # synthetic stereo: shard g = seed (2, g) (N=1: seed 2); right halo = head of the next shard
-        x = synth(own, 2 if world == 1 else (2, rank))
+        x = synth(own, seed if world == 1 else (seed, rank))
         if t_in > own:
-            x = np.concatenate([x, synth(shards[rank + 1].own_len, (2, rank + 1))[:t_in - own]])
+            x = np.concatenate([x, synth(shards[rank + 1].own_len, (seed, rank + 1))[:t_in - own]])
         d_in = plan.alloc(t_in * 8)
         d_out = [plan.alloc((own + spill) * 4) for _ in range(3)]
         plan.h2d(d_in, x)
@@ -417,20 +489,26 @@ def main():
             label = f"bands {g}..{g + n - 1} (STFT {sizes[g]})"
             k_ov = -(-sizes[g] // hops[g])
             a_name = plan.band_phase_kernel_name(g, 0)
+            fill = plan.band_fill(g)
             if a_name:
                 s_name = plan.band_phase_kernel_name(g, 1)
                 launches.append({"kernel": a_name, "bands": label, "ms": float(ana_sum[g]) / n_calls,
+                                 "workgroups": fill["workgroups_analysis"], "slots": fill["slots_analysis"],
                                  "algo_bytes": ALGO_BYTES_IN * own * n,
                                  "flops_executed": executed_flops_per_sample(a_name, sizes[g], k_ov, n, 0) * own})
                 launches.append({"kernel": s_name, "bands": label,
+                                 "workgroups": fill["workgroups"], "slots": fill["slots"],
                                  "ms": float(syn_sum[g]) / n_calls, "algo_bytes": ALGO_BYTES_OUT * own * n,
                                  "flops_executed": executed_flops_per_sample(s_name, sizes[g], k_ov, n, 1) * own})
             else:
                 name = plan.band_kernel_name(g)
                 launches.append({"kernel": name, "bands": label, "ms": float(band_ms[g]),
+                                 "workgroups": fill["workgroups"], "slots": fill["slots"],
                                  "algo_bytes": (ALGO_BYTES_IN + ALGO_BYTES_OUT) * own * n,
                                  "flops_executed": executed_flops_per_sample(name, sizes[g], k_ov, n, 1) * own})
         for L in launches:
+            # how much of the chip the launch fills: workgroups dispatched / workgroup slots resident at once
+            L["fill"] = round(L["workgroups"] / L["slots"], 3) if L.get("slots") else None
             L["GBps"] = round(L["algo_bytes"] / (L["ms"] * 1e-3) / 1e9, 1) if L["ms"] > 0 else None
             L["frac"] = round(L["GBps"] / HBM_PEAK_GBPS, 4) if L["GBps"] else None
             # executed arithmetic of this launch against the f32 vector peak, and its HBM traffic from the PMC counters
@@ -453,7 +531,7 @@ def main():
         flops_executed = sum(L["flops_executed"] for L in launches)
         calls_samples = own                                                            # samples per process_device call
         out = {
-            "metric": "stereo Msamples/sec upmixed (6-band, STFT<=8192)",
+            "metric": f"stereo Msamples/sec upmixed ({n_bands}-band, STFT<={max(sizes)})",
             "value": round(value, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -473,9 +551,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{cfg_name}: " + (f"{TRACKS_PER_GPU} tracks of " if batch else "") +
-                            f"{seconds:g} s of {sr // 1000} kHz stereo per GPU, 6 bands "
-                            f"(edges 0/30/120/480/1920/7680 Hz), STFT {sizes}, Blackman-Harris 75% WOLA, "
-                            f"raised-cosine crossovers XO 0.25, export Ls/C/Rs planes",
+                            f"{seconds:g} s of {sr // 1000} kHz stereo per GPU, {n_bands} band{'s' if n_bands > 1 else ''} "
+                            f"(edges {'/'.join(f'{b.f_low:g}' for b in bands)}/{bands[-1].f_high:g} Hz), STFT {sizes}, "
+                            f"Blackman-Harris 75% WOLA, raised-cosine crossovers XO 0.25, export Ls/C/Rs planes",
                 "name": args.workload,
                 "samples_per_gpu": samples_per_step_rank,
                 "x_realtime": round(total_samples / sr / (elapsed / args.steps), 1),
@@ -552,7 +630,7 @@ def main():
                                           "tracks overlap; best of 3; PCIe-inclusive (never `value`)"}
                     del tracks
                 else:
-                    out["e2e"] = e2e_rates(ux, plan, bands, sr, nominal)
+                    out["e2e"] = e2e_rates(ux, plan, bands, sr, nominal, seed)
                     if args.workload == "c4share":
                         out["e2e"].update(e2e_multi_gpu_file(bands, sr, nominal, local_rank))
             except Exception as exc:   # a side measurement must not take the bench line down
@@ -560,7 +638,7 @@ def main():
         else:
             out["e2e"] = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sr, max_stft)
+            out["cpu_baseline"] = cpu_baseline(args.workload)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
@@ -573,4 +651,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -151,6 +151,12 @@ int upx_plan_band_phase_kernel_name(upx_plan* plan, int band, int phase, char* n
 /* Kernel symbol name / launch geometry of a band (for profiles and DESIGN.md). */
 int upx_plan_band_info(upx_plan* plan, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,
                        int32_t* blocks_per_stream);
+/* How much of the chip the last upx_process_device call's launch of `band` (its merged group) filled: workgroups of the
+   main kernel (fused kernel, or the band-limited synthesis: first launch pair) and the workgroup slots the chip holds of
+   that kernel at once (CUs x resident workgroups per CU by registers and LDS); the same for the band-limited analysis
+   (0 / 0 for single-kernel bands).  workgroups < slots: the launch leaves CUs idle (short signals, bench.py c1 / c2). */
+int upx_plan_band_fill(upx_plan* plan, int band, int32_t* workgroups, int32_t* slots, int32_t* workgroups_analysis,
+                       int32_t* slots_analysis);
 /* Name of the kernel that carries `band`, as rocprofv3 prints it (NUL-terminated, truncated to n bytes):
    "upx_band_kernel<upx::WideCfg<13, 4>, 2>", "upx_band_kernel<upx::Cfg<10, 4, 16>, 2>",
    "upx_zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 4>>" for the band-limited two-kernel path (its analysis kernel:

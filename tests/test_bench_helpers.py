@@ -44,10 +44,51 @@ def test_committed_pmc_summary_names_every_c3_kernel():
 
 
 def test_workload_table():
-    assert set(bench.WORKLOADS) == {"c3", "default", "c4share", "batch"}
-    sr, seconds, max_stft, _ = bench.WORKLOADS["c3"]
+    assert set(bench.WORKLOADS) == {"c1", "c2", "c3", "default", "c4share", "batch"}
+    sr, seconds, max_stft = bench.WORKLOADS["c3"][:3]
     assert (sr, seconds, max_stft) == (48000, 600, 8192)            # BASELINE configs[2]
     assert bench.WORKLOADS["c4share"][:3] == (96000, 900, 8192)     # 2 h at 96 kHz over 8 GPUs
     assert bench.TRACKS_PER_GPU * 8 == 64                           # configs[4]
     x = bench.synth(1000, 2)
     assert x.shape == (1000, 2) and x.dtype.name == "float32"
+
+
+def test_named_shapes_of_configs_0_and_1():
+    """--workload c1 / c2 build the plans SURVEY.md 8 states for BASELINE configs[0] / [1] (the oracle's constructors here;
+    bench.py hands upmix_amd's the same arguments)."""
+    from oracle import upmix_oracle as orc
+    chain = lambda e, sr, m, f: orc.plan_bands(e, 0.75, orc.win_blackman_harris, sr, max_block_size=m, threshold_factor=f)  # noqa: E731
+    (b,) = bench.workload_bands("c1", orc.Band, chain)
+    assert (b.block_size, b.hop_size, b.f_low, b.f_high) == (2048, 512, 0.0, 24000.0)
+    assert bench.WORKLOADS["c1"][:2] == (48000, 10) and bench.WORKLOADS["c1"][6] == 0          # 480 000 samples, seed 0
+    c2 = bench.workload_bands("c2", orc.Band, chain)
+    assert [x.block_size for x in c2] == [4096, 4096, 1024] and bench.WORKLOADS["c2"][:2] == (48000, 60)
+    c3 = bench.workload_bands("c3", orc.Band, chain)
+    assert [x.block_size for x in c3] == [8192, 8192, 8192, 4096, 1024, 256]
+
+
+def test_cpu_baseline_states_threads_and_host(monkeypatch):
+    """`cores` reported the band count as if it were the host; the line now says what ran the frame loops
+    (threads = tasks of the reference's ThreadPoolExecutor) AND what the host is (cpus, model, NumPy)."""
+    monkeypatch.setitem(bench.WORKLOADS, "c1", (48000, 1, 2048, "configs[0], 1 s for the test", "single", 32, 0))
+    line = bench.cpu_baseline("c1", target_seconds=0.5)
+    assert line["kind"] == "port" and line["unit"] == "Msamples/s" and line["value"] > 0
+    assert line["cores"] == line["threads_used"] == 1                  # one band -> one task
+    assert line["host_cpus"] == os.cpu_count() and line["numpy"] and "cpu_model" in line
+    assert "WHOLE workload" in line["sample"]
+
+
+def test_bare_gpus_n_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the ranks through upmix_amd.launch.run
+    (fresh children of the same command) and returns their exit code - and never loads the HIP library itself."""
+    import sys
+    from upmix_amd import launch, _lib
+    calls = []
+    monkeypatch.setattr(launch, "run", lambda n, cmd, **kw: calls.append((n, cmd)) or 7)
+    monkeypatch.setattr(_lib, "load", lambda: (_ for _ in ()).throw(AssertionError("the parent touched the library")))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--workload", "c2"])
+    assert bench.main() == 7
+    (n, cmd), = calls
+    assert n == 2 and cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == sys.argv[1:]

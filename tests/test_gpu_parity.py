@@ -9,6 +9,7 @@ plus size-independent properties (silence -> zeros, shard/seam invariance,
 homogeneity).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -911,3 +912,39 @@ def test_golden_band_edge_corner_cases_and_nonfinite_samples(ux, orc):
         ok = np.isfinite(got) & ~touched
         assert ok.sum() > len(h) - 4000
         assert rms(got[ok].astype(np.float64) - ref[ok]) <= TOL
+
+
+def test_baseline_plans_select_the_budgeted_kernels(ux):
+    """The kernels tests/test_register_budget.py holds to their register budget ARE the ones the BASELINE plans select
+    (bench.py workloads c1, c2, c3, c4share, default): every launch of every such plan names a kernel of that list."""
+    import bench
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("upx_register_budget", os.path.join(os.path.dirname(__file__),
+                                                                                     "test_register_budget.py"))
+    budget = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(budget)
+    known = {bench.canonical_kernel_name(k) for k in list(budget.FUSED) + list(budget.ZOOM)}
+    seen = set()
+    for wl in ("c1", "c2", "c3", "c4share", "default"):
+        sr = bench.WORKLOADS[wl][0]
+        bands = bench.workload_bands(
+            wl, lambda n, ov, lo, hi, sr_, mode, wlo, whi: ux.MultiBandExtractorAccu(n, ov, ux.make_blackman_harris, lo, hi,
+                                                                                    sr_, mode, wlo, whi),
+            lambda e, sr_, m, f: ux.chain_bands(e, 0.75, ux.make_blackman_harris, sr_, max_block_size=m, threshold_factor=f,
+                                                verbose=False))
+        plan = ux.DevicePlan(bands)
+        try:
+            x = np.zeros((sr, 2), np.float32)
+            plan.process(x)                                        # (a call, so that the fill figures exist too)
+            for b in range(len(bands)):
+                names = [plan.band_phase_kernel_name(b, 1)]
+                if plan.band_phase_kernel_name(b, 0):
+                    names.append(plan.band_phase_kernel_name(b, 0))
+                for n in names:
+                    assert bench.canonical_kernel_name(n) in known, (wl, b, n)
+                    seen.add(bench.canonical_kernel_name(n))
+                fill = plan.band_fill(b)
+                assert 0 < fill["workgroups"] and fill["slots"] >= 256
+        finally:
+            plan.close()
+    assert seen == known, known - seen                            # and the list holds nothing no plan selects

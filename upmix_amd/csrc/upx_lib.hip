@@ -222,6 +222,9 @@ struct BandState {
     int group_size = 1;                 // leader: bands merged into its launch; merged members: 0
     int n_gain = 1;                     // gain slots per bin (merged bands overlap at crossovers)
     int last_wg = 0, last_f = 0;
+    // launch geometry of the last call against the chip: workgroups of the (first) launch of the main kernel / of the
+    // band-limited analysis and the workgroup slots the chip holds of them at once (upx_plan_band_fill)
+    int fill_wg = 0, fill_slots = 0, fill_wg_a = 0, fill_slots_a = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // current slot of the rings below
     std::vector<hipEvent_t> ring0, ring1;       // kTimingSlots event pairs: one per recent upx_process_device call
     std::vector<char> ring_used;
@@ -252,6 +255,7 @@ struct upx_plan {
     int knob_zoom_a_age = 8;                // UPX_ZOOM_A_AGE: % by which each later dispatch round of the band-limited analysis runs slower (0 = equal shares)
     int knob_zoom_edge_percent = 76;        // UPX_ZOOM_EDGE_PERCENT: length of the first / last synthesis stream of a signal (100 = like the others)
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
+    int knob_min_stream_frames = 4;         // UPX_MIN_STREAM_FRAMES: shortest stream of a fused launch that does not fill the chip (>= K, even)
     int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
     float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
     size_t seam_floats = 0;
@@ -425,6 +429,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_STREAM_CHUNK")) p->knob_stream_chunk = std::atoll(e);
     if (const char* e = std::getenv("UPX_EDGE_PERCENT")) p->knob_edge_percent = std::atoi(e);
     if (const char* e = std::getenv("UPX_PRIO_YOUNG")) p->knob_prio_young = std::atoi(e);
+    if (const char* e = std::getenv("UPX_MIN_STREAM_FRAMES")) p->knob_min_stream_frames = std::atoi(e);
     if (const char* e = std::getenv("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
     if (const char* e = std::getenv("UPX_ZOOM_C_COST")) p->knob_zoom_c_cost = std::atof(e);
     if (const char* e = std::getenv("UPX_ZOOM_EDGE_PERCENT")) p->knob_zoom_edge_percent = std::atoi(e);
@@ -1009,6 +1014,12 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                     a.prio_split_s = (p->knob_prio_young > 0 && L.once && res_s >= 2 && res_s <= 4) ? p->n_cu : 0;
                     a.prio_rounds_s = res_s;
                 }
+                if (n_launches == 0) {
+                    s.fill_wg = (int)((L.ns_lr + L.ns_c) * groups);
+                    s.fill_slots = p->n_cu * res_s;
+                    s.fill_wg_a = (int)(8 * per_xcd);
+                    s.fill_slots_a = (int)slots;
+                }
                 if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
                 s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
                 if (split) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
@@ -1028,7 +1039,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         // least K (a stream's tail must end inside the next stream).  Streams cover frames m_lo-1 .. m_hi-1.
         const long long target_streams = max_auto_streams(p, s);
         long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + 1 + target_streams - 1) / target_streams;
-        if (s.blocks_override <= 0 && f < 8) f = 8;
+        if (s.blocks_override <= 0 && f < p->knob_min_stream_frames) f = p->knob_min_stream_frames;
         if (f < s.k) f = s.k;
         f += f & 1;
         long long n_streams = (m_hi + 1 + f - 1) / f;
@@ -1120,6 +1131,9 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         a.prio_young = p->knob_prio_young;
         s.last_wg = (int)n_wg;
         s.last_f = (int)f;
+        s.fill_wg = (int)n_wg;
+        s.fill_slots = (int)slots;
+        s.fill_wg_a = s.fill_slots_a = 0;
         if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
         s.kern->launch(a, (int)n_wg, p->stream);
         if (n_streams > 1)
@@ -1468,6 +1482,17 @@ int upx_plan_band_info(upx_plan* p, int band, int32_t* workgroups, int32_t* thre
     if (threads) *threads = s.zoom ? s.zoom->wg : (s.kern ? s.kern->wg : s.big->row_wg);
     if (lds_bytes) *lds_bytes = s.zoom ? s.zoom->lds_bytes : (s.kern ? s.kern->lds_bytes : s.big->row_lds);
     if (blocks_per_stream) *blocks_per_stream = s.last_f;
+    return UPX_OK;
+}
+
+int upx_plan_band_fill(upx_plan* p, int band, int32_t* workgroups, int32_t* slots, int32_t* workgroups_analysis,
+                       int32_t* slots_analysis) {
+    if (!p || band < 0 || band >= (int)p->bands.size()) return fail(UPX_ERR_INVALID, "upx_plan_band_fill: bad argument");
+    const BandState& s = p->bands[p->bands[band].group_leader];
+    if (workgroups) *workgroups = s.fill_wg;
+    if (slots) *slots = s.fill_slots;
+    if (workgroups_analysis) *workgroups_analysis = s.fill_wg_a;
+    if (slots_analysis) *slots_analysis = s.fill_slots_a;
     return UPX_OK;
 }
 

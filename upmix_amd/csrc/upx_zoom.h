@@ -209,6 +209,13 @@ UPX_HD void zoom_ramp_mul(const UPX_GLOBAL cf* seeds, int r, int sl, cf* x, V v)
     put(7, cmul(r6, q1));
 }
 
+// `left` samples remain from a (uniform) position to the end of a buffer: the lanes' own offsets o < 2^29 are inside iff
+// o < zoom_limit(left) - a 32-bit compare against a uniform, where (long long)o < left keeps a 64-bit copy of o alive
+// through the whole transform loop (it was the band-limited synthesis' only spill: 2-5 dwords on the signal-edge body)
+UPX_HD unsigned zoom_limit(long long left) {
+    return left <= 0 ? 0u : (left > 0x7fffffffLL ? 0x7fffffffu : (unsigned)left);
+}
+
 struct ZoomYes { static constexpr bool value = true; };
 struct ZoomNo { static constexpr bool value = false; };
 
@@ -356,8 +363,7 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
         } else {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const long long left = (long long)a.t_in - (base + s * stride);   // uniform
-                const bool inside = (long long)o < left;
+                const bool inside = o < zoom_limit((long long)a.t_in - (base + s * stride));   // (uniform limit)
                 th.pre[s] = gat_u(in, inside ? base + s * stride : 0, inside ? o : 0u);
                 const float w = gat_u(w_a, s * stride, o);
                 th.acc_c[s] = inside ? w : 0.f;
@@ -583,8 +589,8 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
         } else if (h.emit) {
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
-                const long long left = (long long)a.t_out - (h.base + s * (long long)stride);
-                if ((long long)h.o < left) old[s] = gat_u(plane, h.base + s * (long long)stride, h.o);
+                if (h.o < zoom_limit((long long)a.t_out - (h.base + s * (long long)stride)))
+                    old[s] = gat_u(plane, h.base + s * (long long)stride, h.o);
             }
         }
     };
@@ -592,8 +598,8 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
         if (h.fast) {
             store_nt(gat_u(plane, h.base + s * (long long)stride, h.o), v);
         } else if (h.emit) {
-            const long long left = (long long)a.t_out - (h.base + s * (long long)stride);
-            if ((long long)h.o < left) gat_u(plane, h.base + s * (long long)stride, h.o) = v;
+            if (h.o < zoom_limit((long long)a.t_out - (h.base + s * (long long)stride)))
+                gat_u(plane, h.base + s * (long long)stride, h.o) = v;
         }
     };
     // old plane values of the hop(s) transform t emits -> o8[] (Ls/Rs: (old_l, old_r) per slot; C: (old of a, old of b))

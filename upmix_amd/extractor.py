@@ -188,6 +188,14 @@ class DevicePlan:
         return {"workgroups": v[0].value, "threads": v[1].value, "lds_bytes": v[2].value,
                 "blocks_per_stream": v[3].value}
 
+    def band_fill(self, band: int) -> dict:
+        """Workgroups of the last call's launch of `band` against the workgroup slots the chip holds at once (main kernel /
+        band-limited analysis): upx_plan_band_fill."""
+        v = [C.c_int32() for _ in range(4)]
+        _lib.check(self._lib.upx_plan_band_fill(self.handle, int(band), *(C.byref(i) for i in v)))
+        return {"workgroups": v[0].value, "slots": v[1].value, "workgroups_analysis": v[2].value,
+                "slots_analysis": v[3].value}
+
     def band_kernel_name(self, band: int) -> str:
         """Kernel symbol (as rocprofv3 prints it) of the launch that carries `band`."""
         buf = C.create_string_buffer(160)
