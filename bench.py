@@ -263,8 +263,10 @@ def e2e_rates(ux, plan, bands, sr, nominal, seed=2):
     dt = timed(fn)
     t = plan.wav_pipeline_times_ms()
     out["upx_wav_pipeline_pcm16_stereo_sum"] = {"ms": round(dt * 1e3, 2), "Msamples_per_s": round(nominal / dt / 1e6, 1),
-                                                "h2d_ms": round(t["h2d"], 2), "device_ms": round(t["device"], 2),
-                                                "d2h_ms": round(t["d2h"], 2)}
+                                                "begin_ms": round(t["begin"], 2), "begin_tail_ms": round(t["begin_tail"], 2),
+                                                "finish_ms": round(t["finish"], 2),
+                                                "note": "begin = upload || decode || bands || peaks, chunk by chunk; begin_tail = "
+                                                        "what of it came after the last sample landed; finish = export || download"}
     out["note"] = ("pageable input buffers; best of 3; PCIe-inclusive, reported beside `value` (which is HBM-resident), "
                    "SURVEY.md 8(d)")
     return out

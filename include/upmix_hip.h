@@ -198,25 +198,62 @@ int upx_wav_pipeline(upx_plan* plan, const void* pcm_in, int in_format, int chan
 /*
  * The same flow for ONE TIME SHARD of a file (one process per GPU; main.py:43-157 on a slice): the two
  * scalars of main.py:53-55 / :85-88 are global, so the call is split where they cross the ranks.
- *   begin   raw samples of the shard (t_in frames from its first owned one: own range + right halo) go up in pieces,
- *           each decoded as it lands; all bands; the RCCL overlap-add seam if `comm` has more than one rank
+ *   begin   raw samples of the shard (t_in frames from its first owned one: own range + right halo) go up in chunks of
+ *           UPX_WAV_CHUNK owned frames (2^22; on the shard grid); chunk c is decoded and runs through all bands while
+ *           chunk c + 1 comes up (chunk seams as in upx_process_chunked: <= 1e-7 on the K-1 blocks behind a seam); the
+ *           RCCL overlap-add seam if `comm` has more than one rank
  *           (upx_comm_seam_exchange with `spill`; planes hold t_out >= own_len frames, own_len + spill for a shard with
  *           a successor); then peaks[0] = max |input| and peaks[1] = max(|Ls|,|C|,|Rs|) over the OWNED frames (a NaN
  *           anywhere gives NaN, as np.max does).  The caller takes the maximum of both over the ranks.
- *   finish  planes * scale (main.py:95-97), export layout + quantisation on the device (as upx_wav_pipeline), the
- *           final 2-channel sample data of the own_len owned frames comes down into out0..2.
+ *   finish  planes * scale (main.py:95-97), export layout + quantisation on the device (as upx_wav_pipeline), piece by
+ *           piece, each piece's final 2-channel sample data coming down into out0..2 while the next one is exported.
  * upx_wav_pipeline is begin + finish for a shard that is the whole file.
  */
 int upx_wav_shard_begin(upx_plan* plan, upx_comm* comm, const void* pcm_in, int in_format, int channels, int64_t t_in,
                         int64_t own_len, int64_t t_out, int64_t spill, double* peaks);
 int upx_wav_shard_finish(upx_plan* plan, double scale, int mode, int out_format, void* out0, void* out1, void* out2);
+/*
+ * The same two halves for a caller that streams FILE -> GPU -> FILE (multi_gpu.run_rank; main.py:43, :119-153 around the
+ * device): the reads of the input file overlap the uploads, the writes of the output files overlap the downloads.
+ *   open / feed / seal = begin with the shard's samples handed over in order, in pieces of any length: a piece is
+ *       queued for upload as soon as it is fed (it must stay valid and unchanged until upx_wav_shard_seal returns;
+ *       page-locked memory - upx_host_alloc - makes the upload asynchronous), and every chunk whose input is complete
+ *       runs behind it.  seal: the RCCL seam, the peaks (as begin).
+ *   finish_async = finish that returns once everything is queued: piece k (piece_frames frames each, 0 = the plan's
+ *       UPX_WAV_CHUNK; *n_pieces of them) of out0..2 is valid after upx_wav_shard_wait_piece(plan, k); pieces land in order.
+ */
+int upx_wav_shard_open(upx_plan* plan, upx_comm* comm, int in_format, int channels, int64_t t_in, int64_t own_len,
+                       int64_t t_out, int64_t spill);
+int upx_wav_shard_feed(upx_plan* plan, const void* pcm, int64_t n_frames);
+int upx_wav_shard_seal(upx_plan* plan, double* peaks);
+int upx_wav_shard_finish_async(upx_plan* plan, double scale, int mode, int out_format, void* out0, void* out1, void* out2,
+                               int64_t piece_frames, int32_t* n_pieces);
+int upx_wav_shard_wait_piece(upx_plan* plan, int32_t piece);
 /* Between begin and finish: the device planes of the open shard (plane length t_out, the first own_len samples owned) - for
    a seam applied by the caller (upx_seam_add_local between two shards on one device: long files on one GPU, and the
    one-GPU test of the sharded pipeline) - and the peaks of the owned range recomputed after such a seam. */
 int upx_wav_shard_planes(upx_plan* plan, float** d_c, float** d_l, float** d_r, int64_t* own_len, int64_t* t_out);
 int upx_wav_shard_peaks(upx_plan* plan, double* peaks);
-/* Milliseconds spent in the last upx_wav_pipeline call: H2D, decode+kernels+peak+export, D2H. */
+/* Host wall-clock milliseconds of the last upx_wav_shard_begin / _finish (= upx_wav_pipeline) on this plan:
+   ms3[0] = begin (samples up, chunk by chunk, while the previous chunk is decoded and runs through the bands; peaks),
+   ms3[1] = the part of begin that came after the last sample had landed (the last chunk's kernels: what is not hidden),
+   ms3[2] = finish (export layout + quantisation piece by piece while the previous piece goes down). */
 int upx_wav_pipeline_times_ms(upx_plan* plan, float* ms3);
+
+/*
+ * Block-at-a-time streaming: MultiBandExtractorAccu.process_stereo_chunk / flush_final (center_extraction.py:353-424)
+ * for a plan that holds ONE band.  The overlap-add accumulators of :269-271 live on the device as a ring [3][N]:
+ *   upx_stream_chunk  one block of up to N samples per channel (shorter: zero-extended) goes up, the frame is
+ *                     transformed (rfft x2, band limit, mask, irfft x3), added onto the ring, and the ring's first hop
+ *                     samples come down: 2 N floats up, 3 hop floats down per call (round 3: 3 N down, OLA on the host);
+ *                     same float32 additions in the same order as `accum += rec; emit accum[:hop]; shift`.
+ *   upx_stream_state  the accumulators in natural order (what :411-424 returns); clear != 0 also zeroes them = flush_final.
+ *   upx_stream_set_state  overwrite them (a caller that assigns to .accumC / .accumL / .accumR).
+ */
+int upx_stream_chunk(upx_plan* plan, const float* block_l, int32_t n_l, const float* block_r, int32_t n_r, float* out_c,
+                     float* out_l, float* out_r);
+int upx_stream_state(upx_plan* plan, float* acc_c, float* acc_l, float* acc_r, int clear);
+int upx_stream_set_state(upx_plan* plan, const float* acc_c, const float* acc_l, const float* acc_r);
 
 /* ---- multi-GPU seam exchange over RCCL (one process per GPU) ------------ */
 #define UPX_UNIQUE_ID_BYTES 128

@@ -948,3 +948,77 @@ def test_baseline_plans_select_the_budgeted_kernels(ux):
         finally:
             plan.close()
     assert seen == known, known - seen                            # and the list holds nothing no plan selects
+
+
+def test_wav_pipeline_chunked_overlap_equals_single_chunk(ux, monkeypatch):
+    """Round 4: upx_wav_shard_begin / _finish run the shard chunk by chunk (chunk c's kernels under the upload of chunk
+    c + 1, export pieces under the download of the previous piece).  With a small UPX_WAV_CHUNK the same file goes through
+    12 chunks: payload, peaks and scale equal the one-chunk pipeline's except <= 1 LSB behind chunk seams (the float32
+    association of the overlap-add there, as between the chunks of upx_process_chunked); every mode and codec, a mono
+    file, and the sharded form with a caller-applied seam."""
+    from upmix_amd import _lib
+    rng = np.random.default_rng(41)
+    total = 400_000
+    x = np.clip(0.2 * rng.standard_normal((total, 2)), -0.99, 0.99)
+    pcm16 = np.rint(x * 32767).astype("<i2")
+    f32 = x.astype(np.float32)
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 48000, max_block_size=8192,
+                           verbose=False)
+    monkeypatch.setenv("UPX_WAV_CHUNK", "0")
+    whole = ux.DevicePlan(bands)
+    monkeypatch.setenv("UPX_WAV_CHUNK", "32768")          # >= 4 x spill (6144), a multiple of the grid (4096)
+    cut = ux.DevicePlan(bands)
+    try:
+        for src, in_kind, ch in ((pcm16, _lib.PCM16, 2), (f32, _lib.F32, 2), (pcm16[:, 0].copy(), _lib.PCM16, 1)):
+            for mode, out_kind, dt in (("stereo_sum", _lib.PCM16, "<i2"), ("split", _lib.PCM32, "<i4"), ("AB", _lib.F32, "<f4")):
+                ref, ref_stats = whole.wav_pipeline(src, in_kind, ch, total, mode, out_kind)
+                got, stats = cut.wav_pipeline(src, in_kind, ch, total, mode, out_kind)
+                assert stats["peak_in"] == ref_stats["peak_in"]
+                assert abs(stats["overall_peak"] - ref_stats["overall_peak"]) <= 1e-6 * ref_stats["overall_peak"]
+                for key in ref:
+                    a = np.frombuffer(bytes(got[key]), dtype=dt).astype(np.float64)
+                    b = np.frombuffer(bytes(ref[key]), dtype=dt).astype(np.float64)
+                    assert a.shape == b.shape
+                    tol = {"<i2": 1, "<i4": 1 << 17, "<f4": 2e-6}[dt]       # ~1e-7 of full scale behind a seam
+                    assert np.max(np.abs(a - b)) <= tol, (mode, key, float(np.max(np.abs(a - b))))
+                    if dt == "<i2":
+                        assert np.count_nonzero(a != b) <= 64, (mode, key)
+        t = cut.wav_pipeline_times_ms()
+        assert t["begin"] > 0 and t["finish"] > 0 and 0 <= t["begin_tail"] <= t["begin"]
+    finally:
+        whole.close()
+        cut.close()
+
+
+def test_streaming_chunks_on_the_device_ring(ux, orc):
+    """Round 4: process_stereo_chunk keeps the overlap-add accumulators on the device (upx_stream_chunk: 2 N floats up,
+    3 hop floats down per block).  Driven block by block the way the reference drives it (center_extraction.py:449-460:
+    one block per hop, flush at the end), it gives the whole-signal result - the oracle's within tolerance, and
+    process_all_blocks' to float32 rounding (that path pairs frames for the centre transform; this one transforms one
+    frame alone) -, short final blocks included; the accumulator attributes read and write the device state."""
+    for n, total in ((1024, 9000), (256, 2500), (4096, 30000)):
+        hop = n // 4
+        x = orc.synthetic_stereo(total, (9, n))
+        bex = ux.MultiBandExtractorAccu(n, 0.75, ux.make_blackman_harris, 300.0, 3000.0, 48000, "raised_cosine", 75.0, 750.0)
+        ob = orc.Band(n, 0.75, 300.0, 3000.0, 48000, "raised_cosine", 75.0, 750.0)
+        outs = [[], [], []]
+        for idx in range(0, total, hop):                      # (the reference pads to whole blocks; short blocks are
+            parts = bex.process_stereo_chunk(x[idx:idx + n, 0], x[idx:idx + n, 1])   # zero-extended by the library)
+            for o, q in zip(outs, parts):
+                assert q.shape == (hop,) and q.dtype == np.float32
+                o.append(q)
+        assert bex.accumC.shape == (n,) and bex.accumC.any()                        # state lives on, readable
+        tail = bex.flush_final()
+        assert not bex.accumC.any() and not bex.accumL.any()
+        got = [np.concatenate(o + [t])[:total] for o, t in zip(outs, tail)]
+        ref = orc.band_process(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+        whole = bex.process_all_blocks(x[:, 0], x[:, 1])
+        for g, r, w in zip(got, ref, whole):
+            close(g, r)
+            assert rms(g.astype(np.float64) - w) < 1e-7
+        # a caller that presets an accumulator (attribute assignment) sees it emitted with the next block
+        bex.accumL = np.full(n, 0.25, np.float32)
+        c, l, r = bex.process_stereo_chunk(np.zeros(n, np.float32), np.zeros(n, np.float32))
+        assert np.all(l == 0.25) and not c.any()
+        assert np.all(bex.accumL[:n - hop] == 0.25) and not bex.accumL[n - hop:].any()
+        bex.close()

@@ -295,3 +295,47 @@ def test_sharded_device_pipeline_two_shards_on_one_gpu(tmp_path, total):
     finally:
         for p in plans + [whole]:
             p.close()
+
+
+@pytest.mark.gpu
+def test_streamed_file_to_file_in_pieces(tmp_path, monkeypatch):
+    """run_rank streams file -> GPU -> file: pieces are read by a few threads and fed in order (upx_wav_shard_open / _feed /
+    _seal), the second half is queued at once (upx_wav_shard_finish_async) and every piece is written as soon as it has
+    come down.  With 50 000-frame pieces and 32 768-frame device chunks a 300 000-frame file takes 6 reads, 9 chunks and 6
+    writes per output: the files equal the one-piece, one-chunk run's except <= 1 LSB behind chunk seams."""
+    tmp = str(tmp_path)
+    os.makedirs(os.path.join(tmp, "in"))
+    make_wav(os.path.join(tmp, "in", "song.wav"), total=300000, seed=5, subtype="PCM_24")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    args = lambda out, mode, sub: ["song.wav", "--export-mode", mode, "--in-dir", os.path.join(tmp, "in"), "--out-dir", out,  # noqa: E731
+                                   "--max-stft", "8192", "--subtype", sub]
+    for mode, sub, dt in (("stereo_sum", "PCM_16", "<i2"), ("split", "PCM_24", None), ("AB", "FLOAT", "<f4")):
+        monkeypatch.setenv("UPX_WAV_CHUNK", "0")
+        monkeypatch.setattr(multi_gpu, "PIECE_FRAMES", 1 << 22)
+        assert multi_gpu.main(args(os.path.join(tmp, "one"), mode, sub)) == 0
+        monkeypatch.setenv("UPX_WAV_CHUNK", "32768")
+        monkeypatch.setattr(multi_gpu, "PIECE_FRAMES", 50000)
+        assert multi_gpu.main(args(os.path.join(tmp, "cut"), mode, sub)) == 0
+        names = sorted(os.listdir(os.path.join(tmp, "one")))
+        assert names == sorted(os.listdir(os.path.join(tmp, "cut"))) and names
+        for name in names:
+            a = open(os.path.join(tmp, "one", name), "rb").read()
+            b = open(os.path.join(tmp, "cut", name), "rb").read()
+            off = wav.info(os.path.join(tmp, "one", name))["data_offset"]
+            assert len(a) == len(b) and a[:off] == b[:off]
+            if dt is None:                                       # 24 bit: compare as integers
+                ua = np.frombuffer(a[off:], np.uint8).reshape(-1, 3).astype(np.int32)
+                ub = np.frombuffer(b[off:], np.uint8).reshape(-1, 3).astype(np.int32)
+                va = (ua[:, 0] | ua[:, 1] << 8 | ua[:, 2] << 16)
+                vb = (ub[:, 0] | ub[:, 1] << 8 | ub[:, 2] << 16)
+                va = np.where(va >= 1 << 23, va - (1 << 24), va)
+                vb = np.where(vb >= 1 << 23, vb - (1 << 24), vb)
+                assert np.max(np.abs(va - vb)) <= 2
+            else:
+                va = np.frombuffer(a[off:], dt).astype(np.float64)
+                vb = np.frombuffer(b[off:], dt).astype(np.float64)
+                assert np.max(np.abs(va - vb)) <= (1 if dt == "<i2" else 2e-6)
+        for d in ("one", "cut"):
+            for name in os.listdir(os.path.join(tmp, d)):
+                os.remove(os.path.join(tmp, d, name))

@@ -68,9 +68,18 @@ SIGNATURES = {
     "upx_wav_shard_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                       C.c_int64, C.c_int64, C.POINTER(C.c_double)]),
     "upx_wav_shard_finish": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "upx_wav_shard_open": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    "upx_wav_shard_feed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "upx_wav_shard_seal": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "upx_wav_shard_finish_async": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int64, C.POINTER(C.c_int32)]),
+    "upx_wav_shard_wait_piece": (C.c_int, [C.c_void_p, C.c_int32]),
     "upx_wav_shard_planes": (C.c_int, [C.c_void_p, vpp, vpp, vpp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "upx_wav_shard_peaks": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "upx_wav_pipeline_times_ms": (C.c_int, [C.c_void_p, f32p]),
+    "upx_stream_chunk": (C.c_int, [C.c_void_p, f32p, C.c_int32, f32p, C.c_int32, f32p, f32p, f32p]),
+    "upx_stream_state": (C.c_int, [C.c_void_p, f32p, f32p, f32p, C.c_int]),
+    "upx_stream_set_state": (C.c_int, [C.c_void_p, f32p, f32p, f32p]),
     "upx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "upx_comm_create": (C.c_int, [vpp, C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "upx_comm_destroy": (None, [C.c_void_p]),

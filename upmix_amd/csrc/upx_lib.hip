@@ -162,6 +162,38 @@ __global__ void upx_seam_add_kernel(float* c, float* l, float* r, const float* p
     }
 }
 
+// streaming overlap-add of process_stereo_chunk (center_extraction.py:392-407) on a ring that stays on the device:
+// ring[(pos + i) % n] += rec[i]; the first `hop` samples behind `pos` are emitted and cleared (the reference's shift by
+// `hop` and zero tail is the advance of `pos`).  One thread per (plane, i): the same float32 additions in the same order.
+__global__ void upx_chunk_ola_kernel(const float* rec_c, const float* rec_l, const float* rec_r, float* ring, int n, int hop,
+                                     int pos, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int at = (pos + i) % n;
+    const float* rec[3] = {rec_c, rec_l, rec_r};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = ring[(size_t)k * n + at] + rec[k][i];
+        if (i < hop) {
+            out[(size_t)k * hop + i] = v;
+            ring[(size_t)k * n + at] = 0.f;
+        } else {
+            ring[(size_t)k * n + at] = v;
+        }
+    }
+}
+// ring -> natural order (flush_final, :411-424), optionally clearing it
+__global__ void upx_chunk_unroll_kernel(float* ring, int n, int pos, float* out, int clear) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int at = (pos + i) % n;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        out[(size_t)k * n + i] = ring[(size_t)k * n + at];
+        if (clear) ring[(size_t)k * n + at] = 0.f;
+    }
+}
+
 constexpr int kMidEvents = 15;           // up to 8 launch pairs of the band-limited path are timed per phase
 constexpr int kTimingSlots = 64;          // recent upx_process_device calls whose per-band events are kept
 constexpr int kMaxFramesPerSample = 64;   // unfused path: ceil(N / hop) frames overlap one sample
@@ -277,6 +309,30 @@ struct upx_plan {
     int64_t wav_tin = 0, wav_own = 0, wav_tout = 0;
     int wav_fmt = 0, wav_ch = 0;
     hipEvent_t wav_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // chunked WAV pipeline: owned frames per chunk (UPX_WAV_CHUNK, 0 = one chunk), per-chunk events, the spill of a chunk
+    // parked while the next chunk's kernels overwrite that range, peaks (input, C, Ls, Rs) as bit patterns
+    long long knob_wav_chunk = 1LL << 22;
+    std::vector<hipEvent_t> wav_piece_ev, wav_down_ev;
+    float* d_wav_side[2] = {nullptr, nullptr};
+    size_t wav_side_floats = 0;
+    unsigned int* d_wav_peaks = nullptr;
+    bool wav_peaks_pending_head = false;    // multi-rank: chunk 0's plane peaks wait for the RCCL seam
+    int64_t wav_head_own = 0;
+    // between upx_wav_shard_open and _seal: the chunk list, frames fed / decoded, the next chunk to run
+    struct WavChunkRec { int64_t start, own, t_in, t_out; };
+    bool wav_feeding = false;
+    std::vector<WavChunkRec> wav_chunk_list;
+    int64_t wav_fed = 0, wav_decoded = 0, wav_spill = 0, wav_cspill = 0;
+    int wav_next_chunk = 0, wav_n_feed = 0;
+    upx_comm* wav_comm = nullptr;
+    double wav_t0 = 0.0;
+    // upx_wav_shard_finish_async: pieces on their way down
+    int wav_pieces = 0;
+    // streaming state of a one-band plan (upx_stream_chunk): block in, one frame's three reconstructions, the
+    // overlap-add ring [3][N] with its read position, the emitted hops
+    float* d_chunk = nullptr;        // [2 N] block | [3 N] rec | [3 N] ring | [3 hop] out
+    float* h_chunk = nullptr;        // page-locked: [2 N] block | [3 N] results
+    int chunk_pos = 0;
 };
 
 struct upx_comm {
@@ -430,6 +486,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_EDGE_PERCENT")) p->knob_edge_percent = std::atoi(e);
     if (const char* e = std::getenv("UPX_PRIO_YOUNG")) p->knob_prio_young = std::atoi(e);
     if (const char* e = std::getenv("UPX_MIN_STREAM_FRAMES")) p->knob_min_stream_frames = std::atoi(e);
+    if (const char* e = std::getenv("UPX_WAV_CHUNK")) p->knob_wav_chunk = std::atoll(e);
     if (const char* e = std::getenv("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
     if (const char* e = std::getenv("UPX_ZOOM_C_COST")) p->knob_zoom_c_cost = std::atof(e);
     if (const char* e = std::getenv("UPX_ZOOM_EDGE_PERCENT")) p->knob_zoom_edge_percent = std::atoi(e);
@@ -688,6 +745,12 @@ void upx_plan_destroy(upx_plan* p) {
     }
     for (auto* q : p->d_wav) if (q) (void)hipFree(q);
     for (auto e : p->wav_ev) if (e) (void)hipEventDestroy(e);
+    for (auto e : p->wav_piece_ev) if (e) (void)hipEventDestroy(e);
+    for (auto e : p->wav_down_ev) if (e) (void)hipEventDestroy(e);
+    for (auto* q : p->d_wav_side) if (q) (void)hipFree(q);
+    if (p->d_wav_peaks) (void)hipFree(p->d_wav_peaks);
+    if (p->d_chunk) (void)hipFree(p->d_chunk);
+    if (p->h_chunk) (void)hipHostFree(p->h_chunk);
     if (p->s_h2d) (void)hipStreamDestroy(p->s_h2d);
     if (p->s_d2h) (void)hipStreamDestroy(p->s_d2h);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1564,56 +1627,228 @@ int ensure_copy_streams(upx_plan* p) {
 }
 }   // namespace
 
-int upx_wav_shard_begin(upx_plan* p, upx_comm* comm, const void* pcm_in, int in_format, int channels, int64_t t_in,
-                        int64_t own_len, int64_t t_out, int64_t spill, double* peaks) {
-    if (!p || !pcm_in || !peaks || t_in < 1 || own_len < 1 || own_len > t_in || t_out < own_len || spill < 0 ||
-        (channels != 1 && channels != 2))
-        return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: bad argument");
-    if (!wav_format_ok(in_format)) return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: unknown sample format");
+namespace {
+// One chunk of the WAV pipeline: owned frames [start, start + own) of the shard; its kernels read t_in frames from
+// `start` (own range + right halo) and write t_out (own + spill; the shard's last chunk: what is left of the planes).
+using WavChunk = upx_plan::WavChunkRec;
+
+// Chunks of `chunk` owned frames on the shard grid (as items_of_track cuts a streamed host call): the kernels of chunk c
+// run while the samples of chunk c + 1 come up.  One chunk when the plan's hops share no grid or the shard is short.
+void wav_chunks(const upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out, std::vector<WavChunk>& out) {
+    out.clear();
+    int64_t grid = 0, spill = 0;
+    int64_t chunk = p->knob_wav_chunk;
+    const bool gridded = shard_geometry(p, &grid, &spill);
+    if (chunk > 0 && gridded) {
+        chunk = (chunk + grid - 1) / grid * grid;
+        if (chunk < spill) chunk = (spill + grid - 1) / grid * grid;
+    }
+    if (chunk <= 0 || !gridded || own_len < 2 * chunk || chunk < 4 * spill) {
+        out.push_back(WavChunk{0, own_len, t_in, t_out});
+        return;
+    }
+    const int64_t n = (own_len + chunk - 1) / chunk;
+    for (int64_t c = 0; c < n; ++c) {
+        const int64_t start = c * chunk;
+        const bool last = c == n - 1;
+        WavChunk w;
+        w.start = start;
+        w.own = last ? own_len - start : chunk;
+        w.t_in = t_in - start < w.own + spill ? t_in - start : w.own + spill;
+        w.t_out = last ? t_out - start : w.own + spill;
+        out.push_back(w);
+    }
+}
+
+double wall_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+}   // namespace
+
+int upx_wav_shard_open(upx_plan* p, upx_comm* comm, int in_format, int channels, int64_t t_in, int64_t own_len,
+                       int64_t t_out, int64_t spill) {
+    if (!p || t_in < 1 || own_len < 1 || own_len > t_in || t_out < own_len || spill < 0 || (channels != 1 && channels != 2))
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_open: bad argument");
+    if (!wav_format_ok(in_format)) return fail(UPX_ERR_INVALID, "upx_wav_shard_open: unknown sample format");
     if (t_in >= (1LL << 29) || t_out >= (1LL << 29))
-        return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: at most 2^29-1 frames per shard");
-    if (comm && comm->plan != p) return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: the communicator belongs to another plan");
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_open: at most 2^29-1 frames per shard");
+    if (comm && comm->plan != p) return fail(UPX_ERR_INVALID, "upx_wav_shard_open: the communicator belongs to another plan");
     const bool exchange = comm && comm->n_ranks > 1 && spill > 0;
     if (exchange && comm->rank + 1 < comm->n_ranks && t_out < own_len + spill)
-        return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: planes of a shard with a successor need own_len + spill samples");
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_open: planes of a shard with a successor need own_len + spill samples");
     HIP_TRY(hipSetDevice(p->device));
+    p->wav_t0 = wall_ms();
     p->wav_open = false;
+    p->wav_feeding = false;
     const int width = wav_bytes_of(in_format);
-    const size_t in_bytes = (size_t)t_in * channels * width;
-    HIP_TRY(wav_ensure(p, 0, in_bytes));
+    HIP_TRY(wav_ensure(p, 0, (size_t)t_in * channels * width));
     HIP_TRY(wav_ensure(p, 1, (size_t)t_in * 2 * sizeof(float)));
     HIP_TRY(wav_ensure(p, 2, (size_t)t_out * 3 * sizeof(float)));
     if (int rc = ensure_copy_streams(p)) return rc;
+    for (auto& e : p->wav_ev)
+        if (!e) HIP_TRY(hipEventCreate(&e));
+    if (!p->d_wav_peaks) HIP_TRY(hipMalloc(&p->d_wav_peaks, 4 * sizeof(unsigned int)));
+    // The shard runs chunk by chunk: the samples of chunk c + 1 come up (copy stream) while chunk c is decoded and runs
+    // through every band (plan's stream); a chunk's kernels write own + spill samples of the planes, the spill is parked
+    // in a side row while the next chunk's kernels write that range anew, then added onto it - the chunk seam of
+    // upx_process (run_items) on planes that stay resident, because the one scale of main.py:85-97 needs every peak
+    // before anything can be exported.  The peaks are folded into the same stream (max of bit patterns, one
+    // download of four words at the end).
+    wav_chunks(p, t_in, own_len, t_out, p->wav_chunk_list);
+    p->wav_cspill = 0;
+    int64_t cgrid = 0;
+    if (p->wav_chunk_list.size() > 1) (void)shard_geometry(p, &cgrid, &p->wav_cspill);
+    if (p->wav_chunk_list.size() > 1 && (size_t)(3 * p->wav_cspill) > p->wav_side_floats) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (auto*& q : p->d_wav_side) {
+            if (q) HIP_TRY(hipFree(q));
+            q = nullptr;
+        }
+        p->wav_side_floats = 0;
+        for (auto*& q : p->d_wav_side) HIP_TRY(hipMalloc(&q, (size_t)3 * p->wav_cspill * sizeof(float)));
+        p->wav_side_floats = (size_t)3 * p->wav_cspill;
+    }
+    hipStream_t st = p->stream;
+    HIP_TRY(hipEventRecord(p->wav_ev[0], st));
+    HIP_TRY(hipStreamWaitEvent(p->s_h2d, p->wav_ev[0], 0));   // the previous call's kernels have left the buffers
+    HIP_TRY(hipMemsetAsync(p->d_wav_peaks, 0, 4 * sizeof(unsigned int), st));
+    p->wav_tin = t_in; p->wav_own = own_len; p->wav_tout = t_out;
+    p->wav_fmt = in_format; p->wav_ch = channels;
+    p->wav_comm = exchange ? comm : nullptr;
+    p->wav_spill = spill;
+    p->wav_fed = p->wav_decoded = 0;
+    p->wav_next_chunk = 0;
+    p->wav_n_feed = 0;
+    p->wav_peaks_pending_head = false;
+    p->wav_feeding = true;
+    return UPX_OK;
+}
+
+int upx_wav_shard_feed(upx_plan* p, const void* pcm, int64_t n_frames) {
+    if (!p || !p->wav_feeding) return fail(UPX_ERR_INVALID, "upx_wav_shard_feed: no shard is being fed (call upx_wav_shard_open)");
+    if (!pcm || n_frames < 1 || p->wav_fed + n_frames > p->wav_tin)
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_feed: %lld frames after %lld of %lld", (long long)n_frames,
+                    (long long)p->wav_fed, (long long)p->wav_tin);
+    HIP_TRY(hipSetDevice(p->device));
+    const int width = wav_bytes_of(p->wav_fmt), channels = p->wav_ch;
     unsigned char* d_pcm = (unsigned char*)p->d_wav[0];
     float* d_st = (float*)p->d_wav[1];
     float* d_pl = (float*)p->d_wav[2];
-    for (auto& e : p->wav_ev)
-        if (!e) HIP_TRY(hipEventCreate(&e));
+    const int64_t t_out = p->wav_tout, own_len = p->wav_own, cspill = p->wav_cspill;
+    float* d_plane[3] = {d_pl, d_pl + t_out, d_pl + 2 * t_out};
     hipStream_t st = p->stream;
-    HIP_TRY(hipEventRecord(p->wav_ev[0], st));
-    // the samples go up in pieces on the copy stream; each piece is decoded as soon as it has landed, so the decode
-    // (and, for the first pieces, nothing else) runs beside the rest of the upload
-    HIP_TRY(hipStreamWaitEvent(p->s_h2d, p->wav_ev[0], 0));   // the previous call's kernels have left the buffers
-    const int64_t piece = 1LL << 22;
-    int k = 0;
-    for (int64_t f0 = 0; f0 < t_in; f0 += piece, k ^= 1) {
-        const int64_t nf = t_in - f0 < piece ? t_in - f0 : piece;
-        const size_t off = (size_t)f0 * channels * width;
-        HIP_TRY(hipMemcpyAsync(d_pcm + off, (const unsigned char*)pcm_in + off, (size_t)nf * channels * width,
-                               hipMemcpyHostToDevice, p->s_h2d));
-        HIP_TRY(hipEventRecord(p->ev_h2d[k], p->s_h2d));
-        HIP_TRY(hipStreamWaitEvent(st, p->ev_h2d[k], 0));
-        hipLaunchKernelGGL(upx_decode_kernel, dim3(grid_for(nf)), dim3(256), 0, st, d_pcm + off, in_format, channels,
-                           (long long)nf, d_st + 2 * f0);
+    // the piece goes up on the copy stream ...
+    const size_t off = (size_t)p->wav_fed * channels * width;
+    HIP_TRY(hipMemcpyAsync(d_pcm + off, pcm, (size_t)n_frames * channels * width, hipMemcpyHostToDevice, p->s_h2d));
+    if ((size_t)p->wav_n_feed >= p->wav_piece_ev.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->wav_piece_ev.push_back(e);
     }
-    HIP_TRY(hipEventRecord(p->wav_ev[1], st));
-    if (int rc = upx_process_device(p, d_st, t_in, own_len, d_pl, d_pl + t_out, d_pl + 2 * t_out, t_out)) return rc;
-    if (exchange)
-        if (int rc = upx_comm_seam_exchange(comm, d_pl, d_pl + t_out, d_pl + 2 * t_out, own_len, spill)) return rc;
-    p->wav_tin = t_in; p->wav_own = own_len; p->wav_tout = t_out;
-    p->wav_fmt = in_format; p->wav_ch = channels;
+    hipEvent_t landed = p->wav_piece_ev[(size_t)p->wav_n_feed++];
+    HIP_TRY(hipEventRecord(landed, p->s_h2d));
+    p->wav_fed += n_frames;
+    // ... and every chunk whose input is now complete is queued behind it on the plan's stream
+    bool waited = false;
+    const std::vector<WavChunk>& chunks = p->wav_chunk_list;
+    while ((size_t)p->wav_next_chunk < chunks.size()) {
+        const size_t c = (size_t)p->wav_next_chunk;
+        const WavChunk& w = chunks[c];
+        const int64_t end = w.start + w.t_in;
+        if (end > p->wav_fed) break;
+        if (!waited) HIP_TRY(hipStreamWaitEvent(st, landed, 0));
+        waited = true;
+        const int64_t up = p->wav_decoded;
+        if (end > up) {
+            const size_t o = (size_t)up * channels * width;
+            hipLaunchKernelGGL(upx_decode_kernel, dim3(grid_for(end - up)), dim3(256), 0, st, d_pcm + o, p->wav_fmt, channels,
+                               (long long)(end - up), d_st + 2 * up);
+            const int64_t owned_end = end < own_len ? end : own_len;   // input peak: owned frames only (main.py:53)
+            if (owned_end > up)
+                hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_for(2 * (owned_end - up))), dim3(256), 0, st, d_st + 2 * up,
+                                   (long long)(2 * (owned_end - up)), p->d_wav_peaks);
+            p->wav_decoded = end;
+        }
+        if (c + 1 == chunks.size()) HIP_TRY(hipEventRecord(p->wav_ev[1], st));
+        if (int rc = upx_process_device(p, d_st + 2 * w.start, w.t_in, w.own, d_plane[0] + w.start, d_plane[1] + w.start,
+                                        d_plane[2] + w.start, w.t_out))
+            return rc;
+        if (c > 0) {
+            const float* side = p->d_wav_side[(c - 1) & 1];
+            const int64_t add = cspill < w.t_out ? cspill : w.t_out;
+            hipLaunchKernelGGL(upx_seam_add_kernel, dim3(grid_for(add)), dim3(256), 0, st, d_plane[0] + w.start,
+                               d_plane[1] + w.start, d_plane[2] + w.start, side, side + cspill, side + 2 * cspill, (long long)add);
+        }
+        if (c + 1 < chunks.size())
+            hipLaunchKernelGGL(upx_seam_pack_kernel, dim3(grid_for(cspill)), dim3(256), 0, st, p->d_wav_side[c & 1],
+                               d_plane[0] + w.start, d_plane[1] + w.start, d_plane[2] + w.start, (long long)w.own, (long long)cspill);
+        // plane peaks of the chunk's owned range, final now - except the shard's head under a multi-rank seam
+        if (p->wav_comm && c == 0) {
+            p->wav_peaks_pending_head = true;
+            p->wav_head_own = w.own;
+        } else {
+            for (int k = 0; k < 3; ++k)
+                hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_for(w.own)), dim3(256), 0, st, d_plane[k] + w.start,
+                                   (long long)w.own, p->d_wav_peaks + 1 + k);
+        }
+        p->wav_next_chunk += 1;
+    }
+    HIP_TRY(hipGetLastError());
+    return UPX_OK;
+}
+
+int upx_wav_shard_seal(upx_plan* p, double* peaks) {
+    if (!p || !peaks || !p->wav_feeding) return fail(UPX_ERR_INVALID, "upx_wav_shard_seal: no shard is being fed");
+    if (p->wav_fed != p->wav_tin || (size_t)p->wav_next_chunk != p->wav_chunk_list.size())
+        return fail(UPX_ERR_INVALID, "upx_wav_shard_seal: %lld of %lld frames fed", (long long)p->wav_fed, (long long)p->wav_tin);
+    HIP_TRY(hipSetDevice(p->device));
+    hipStream_t st = p->stream;
+    float* d_pl = (float*)p->d_wav[2];
+    float* d_plane[3] = {d_pl, d_pl + p->wav_tout, d_pl + 2 * p->wav_tout};
+    p->wav_feeding = false;
+    if (p->wav_comm)
+        if (int rc = upx_comm_seam_exchange(p->wav_comm, d_plane[0], d_plane[1], d_plane[2], p->wav_own, p->wav_spill)) return rc;
+    if (p->wav_peaks_pending_head) {
+        for (int k = 0; k < 3; ++k)
+            hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_for(p->wav_head_own)), dim3(256), 0, st, d_plane[k],
+                               (long long)p->wav_head_own, p->d_wav_peaks + 1 + k);
+        p->wav_peaks_pending_head = false;
+    }
     p->wav_open = true;
-    return upx_wav_shard_peaks(p, peaks);
+    unsigned int bits[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(bits, p->d_wav_peaks, sizeof bits, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float pk[4];
+    std::memcpy(pk, bits, sizeof pk);
+    auto fmax_nan = [](float a, float b) { return (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b); };
+    peaks[0] = (double)pk[0];
+    peaks[1] = (double)fmax_nan(fmax_nan(pk[1], pk[2]), pk[3]);
+    // what open .. seal cost on the host's clock, and how much of it came after the last sample had landed on the device
+    float landed_ms = 0.f;
+    (void)hipEventElapsedTime(&landed_ms, p->wav_ev[0], p->wav_ev[1]);
+    p->pipe_ms[0] = (float)(wall_ms() - p->wav_t0);
+    p->pipe_ms[1] = p->pipe_ms[0] - landed_ms > 0.f ? p->pipe_ms[0] - landed_ms : 0.f;
+    return UPX_OK;
+}
+
+int upx_wav_shard_begin(upx_plan* p, upx_comm* comm, const void* pcm_in, int in_format, int channels, int64_t t_in,
+                        int64_t own_len, int64_t t_out, int64_t spill, double* peaks) {
+    if (!p || !pcm_in || !peaks) return fail(UPX_ERR_INVALID, "upx_wav_shard_begin: bad argument");
+    if (int rc = upx_wav_shard_open(p, comm, in_format, channels, t_in, own_len, t_out, spill)) return rc;
+    // one piece per chunk: what chunk c needs beyond chunk c - 1's input (all uploads are queued at once; the kernels of
+    // chunk c wait for piece c only)
+    const size_t frame = (size_t)channels * wav_bytes_of(in_format);
+    int64_t up = 0;
+    const std::vector<WavChunk> chunks = p->wav_chunk_list;
+    for (const WavChunk& w : chunks) {
+        const int64_t end = w.start + w.t_in;
+        if (end <= up) continue;
+        if (int rc = upx_wav_shard_feed(p, (const unsigned char*)pcm_in + (size_t)up * frame, end - up)) return rc;
+        up = end;
+    }
+    return upx_wav_shard_seal(p, peaks);
 }
 
 int upx_wav_shard_peaks(upx_plan* p, double* peaks) {
@@ -1643,7 +1878,8 @@ int upx_wav_shard_planes(upx_plan* p, float** d_c, float** d_l, float** d_r, int
     return UPX_OK;
 }
 
-int upx_wav_shard_finish(upx_plan* p, double scale, int mode, int out_format, void* out0, void* out1, void* out2) {
+int upx_wav_shard_finish_async(upx_plan* p, double scale, int mode, int out_format, void* out0, void* out1, void* out2,
+                               int64_t piece_frames, int32_t* n_pieces) {
     if (!p || !p->wav_open) return fail(UPX_ERR_INVALID, "upx_wav_shard_finish: no shard is open (call upx_wav_shard_begin)");
     if (!wav_format_ok(out_format)) return fail(UPX_ERR_INVALID, "upx_wav_shard_finish: unknown sample format");
     if (mode != UPX_EXPORT_STEREO_SUM && mode != UPX_EXPORT_SPLIT && mode != UPX_EXPORT_AB)
@@ -1659,16 +1895,51 @@ int upx_wav_shard_finish(upx_plan* p, double scale, int mode, int out_format, vo
     unsigned char* d_o[3] = {(unsigned char*)p->d_wav[3], (unsigned char*)p->d_wav[4], (unsigned char*)p->d_wav[5]};
     const float* d_pl = (const float*)p->d_wav[2];
     hipStream_t st = p->stream;
-    hipLaunchKernelGGL(upx_export_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_pl, d_pl + t_out, d_pl + 2 * t_out,
-                       (const unsigned char*)p->d_wav[0], p->wav_fmt, p->wav_ch, (long long)n, scale, mode, out_format,
-                       d_o[0], d_o[1], d_o[2]);
-    HIP_TRY(hipEventRecord(p->wav_ev[2], st));
-    for (int i = 0; i < n_out; ++i) HIP_TRY(hipMemcpyAsync(outs[i], d_o[i], out_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(p->wav_ev[3], st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (int i = 0; i < 3; ++i) (void)hipEventElapsedTime(&p->pipe_ms[i], p->wav_ev[i], p->wav_ev[i + 1]);
+    p->wav_t0 = wall_ms();
+    if (int rc = ensure_copy_streams(p)) return rc;
+    // export layout + quantisation piece by piece; a piece goes down (copy stream) while the next one is exported
+    int64_t piece = piece_frames > 0 ? piece_frames : (p->knob_wav_chunk > 0 ? p->knob_wav_chunk : n);
+    if (piece > n) piece = n;
+    const int64_t pieces = (n + piece - 1) / piece;
+    const size_t frame_bytes = (size_t)2 * wav_bytes_of(out_format);
+    const size_t in_frame_bytes = (size_t)p->wav_ch * wav_bytes_of(p->wav_fmt);
+    while ((int64_t)p->wav_piece_ev.size() < pieces || (int64_t)p->wav_down_ev.size() < pieces) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ((int64_t)p->wav_piece_ev.size() < pieces ? p->wav_piece_ev : p->wav_down_ev).push_back(e);
+    }
+    int k = 0;
+    for (int64_t f0 = 0; f0 < n; f0 += piece, ++k) {
+        const int64_t nf = n - f0 < piece ? n - f0 : piece;
+        hipLaunchKernelGGL(upx_export_kernel, dim3(grid_for(nf)), dim3(256), 0, st, d_pl + f0, d_pl + t_out + f0,
+                           d_pl + 2 * t_out + f0, (const unsigned char*)p->d_wav[0] + (size_t)f0 * in_frame_bytes, p->wav_fmt,
+                           p->wav_ch, (long long)nf, scale, mode, out_format, d_o[0] + (size_t)f0 * frame_bytes,
+                           d_o[1] ? d_o[1] + (size_t)f0 * frame_bytes : nullptr, d_o[2] ? d_o[2] + (size_t)f0 * frame_bytes : nullptr);
+        HIP_TRY(hipEventRecord(p->wav_piece_ev[k], st));
+        HIP_TRY(hipStreamWaitEvent(p->s_d2h, p->wav_piece_ev[k], 0));
+        for (int i = 0; i < n_out; ++i)
+            HIP_TRY(hipMemcpyAsync((unsigned char*)outs[i] + (size_t)f0 * frame_bytes, d_o[i] + (size_t)f0 * frame_bytes,
+                                   (size_t)nf * frame_bytes, hipMemcpyDeviceToHost, p->s_d2h));
+        HIP_TRY(hipEventRecord(p->wav_down_ev[k], p->s_d2h));
+    }
+    HIP_TRY(hipGetLastError());
+    p->wav_pieces = (int)pieces;
     p->wav_open = false;
+    if (n_pieces) *n_pieces = (int32_t)pieces;
     return UPX_OK;
+}
+
+int upx_wav_shard_wait_piece(upx_plan* p, int32_t piece) {
+    if (!p || piece < 0 || piece >= p->wav_pieces) return fail(UPX_ERR_INVALID, "upx_wav_shard_wait_piece: no such piece");
+    HIP_TRY(hipEventSynchronize(p->wav_down_ev[(size_t)piece]));
+    if (piece == p->wav_pieces - 1) p->pipe_ms[2] = (float)(wall_ms() - p->wav_t0);
+    return UPX_OK;
+}
+
+int upx_wav_shard_finish(upx_plan* p, double scale, int mode, int out_format, void* out0, void* out1, void* out2) {
+    int32_t pieces = 0;
+    if (int rc = upx_wav_shard_finish_async(p, scale, mode, out_format, out0, out1, out2, 0, &pieces)) return rc;
+    return upx_wav_shard_wait_piece(p, pieces - 1);    // (the pieces come down in order on one stream)
 }
 
 int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channels, int64_t n, int mode, int out_format,
@@ -1699,6 +1970,94 @@ int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channel
 int upx_wav_pipeline_times_ms(upx_plan* p, float* ms3) {
     if (!p || !ms3) return fail(UPX_ERR_INVALID, "upx_wav_pipeline_times_ms: bad argument");
     for (int i = 0; i < 3; ++i) ms3[i] = p->pipe_ms[i];
+    return UPX_OK;
+}
+
+// ---- block-at-a-time streaming (MultiBandExtractorAccu.process_stereo_chunk) ------------------------------------
+namespace {
+int chunk_state(upx_plan* p, int* n_out, int* hop_out) {
+    if (p->bands.size() != 1) return fail(UPX_ERR_INVALID, "upx_stream_*: the plan must hold exactly one band");
+    const int n = p->bands[0].n, hop = p->bands[0].hop;
+    if (!p->d_chunk) {
+        HIP_TRY(hipSetDevice(p->device));
+        HIP_TRY(hipMalloc(&p->d_chunk, ((size_t)8 * n + 3 * hop) * sizeof(float)));
+        HIP_TRY(hipHostMalloc(&p->h_chunk, (size_t)5 * n * sizeof(float), hipHostMallocPortable));
+        HIP_TRY(hipMemsetAsync(p->d_chunk + (size_t)5 * n, 0, (size_t)3 * n * sizeof(float), p->stream));
+        p->chunk_pos = 0;
+    }
+    *n_out = n;
+    *hop_out = hop;
+    return UPX_OK;
+}
+}   // namespace
+
+int upx_stream_chunk(upx_plan* p, const float* block_l, int32_t n_l, const float* block_r, int32_t n_r, float* out_c,
+                     float* out_l, float* out_r) {
+    if (!p || !out_c || !out_l || !out_r || n_l < 0 || n_r < 0 || (n_l > 0 && !block_l) || (n_r > 0 && !block_r))
+        return fail(UPX_ERR_INVALID, "upx_stream_chunk: bad argument");
+    int n = 0, hop = 0;
+    if (int rc = chunk_state(p, &n, &hop)) return rc;
+    if (n_l > n || n_r > n) return fail(UPX_ERR_INVALID, "upx_stream_chunk: a block holds at most block_size samples");
+    HIP_TRY(hipSetDevice(p->device));
+    // interleave into the page-locked staging row (short blocks are zero-extended, center_extraction.py:437-455)
+    float* h = p->h_chunk;
+    for (int i = 0; i < n; ++i) {
+        h[2 * i] = i < n_l ? block_l[i] : 0.f;
+        h[2 * i + 1] = i < n_r ? block_r[i] : 0.f;
+    }
+    float* d_blk = p->d_chunk;
+    float* d_rec = d_blk + (size_t)2 * n;
+    float* d_ring = d_rec + (size_t)3 * n;
+    float* d_out = d_ring + (size_t)3 * n;
+    hipStream_t st = p->stream;
+    HIP_TRY(hipMemcpyAsync(d_blk, h, (size_t)2 * n * sizeof(float), hipMemcpyHostToDevice, st));
+    // own_len = 1: only the frame that starts at sample 0 exists; its three reconstructions fill [0, N)
+    if (int rc = upx_process_device(p, d_blk, n, 1, d_rec, d_rec + n, d_rec + 2 * n, n)) return rc;
+    hipLaunchKernelGGL(upx_chunk_ola_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_rec, d_rec + n, d_rec + 2 * n, d_ring,
+                       n, hop, p->chunk_pos, d_out);
+    HIP_TRY(hipGetLastError());
+    float* h_out = h + (size_t)2 * n;
+    HIP_TRY(hipMemcpyAsync(h_out, d_out, (size_t)3 * hop * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    p->chunk_pos = (p->chunk_pos + hop) % n;
+    std::memcpy(out_c, h_out, (size_t)hop * sizeof(float));
+    std::memcpy(out_l, h_out + hop, (size_t)hop * sizeof(float));
+    std::memcpy(out_r, h_out + 2 * hop, (size_t)hop * sizeof(float));
+    return UPX_OK;
+}
+
+int upx_stream_state(upx_plan* p, float* acc_c, float* acc_l, float* acc_r, int clear) {
+    if (!p || !acc_c || !acc_l || !acc_r) return fail(UPX_ERR_INVALID, "upx_stream_state: bad argument");
+    int n = 0, hop = 0;
+    if (int rc = chunk_state(p, &n, &hop)) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    float* d_rec = p->d_chunk + (size_t)2 * n;          // (free between calls: the unrolled ring goes through it)
+    float* d_ring = d_rec + (size_t)3 * n;
+    hipLaunchKernelGGL(upx_chunk_unroll_kernel, dim3((n + 255) / 256), dim3(256), 0, p->stream, d_ring, n, p->chunk_pos, d_rec,
+                       clear ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    float* h = p->h_chunk + (size_t)2 * n;
+    HIP_TRY(hipMemcpyAsync(h, d_rec, (size_t)3 * n * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    std::memcpy(acc_c, h, (size_t)n * sizeof(float));
+    std::memcpy(acc_l, h + n, (size_t)n * sizeof(float));
+    std::memcpy(acc_r, h + 2 * n, (size_t)n * sizeof(float));
+    return UPX_OK;
+}
+
+int upx_stream_set_state(upx_plan* p, const float* acc_c, const float* acc_l, const float* acc_r) {
+    if (!p || !acc_c || !acc_l || !acc_r) return fail(UPX_ERR_INVALID, "upx_stream_set_state: bad argument");
+    int n = 0, hop = 0;
+    if (int rc = chunk_state(p, &n, &hop)) return rc;
+    HIP_TRY(hipSetDevice(p->device));
+    float* h = p->h_chunk + (size_t)2 * n;
+    std::memcpy(h, acc_c, (size_t)n * sizeof(float));
+    std::memcpy(h + n, acc_l, (size_t)n * sizeof(float));
+    std::memcpy(h + 2 * n, acc_r, (size_t)n * sizeof(float));
+    float* d_ring = p->d_chunk + (size_t)5 * n;
+    HIP_TRY(hipMemcpyAsync(d_ring, h, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->chunk_pos = 0;
     return UPX_OK;
 }
 

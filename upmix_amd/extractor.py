@@ -257,6 +257,43 @@ class DevicePlan:
                                                      int(t_in), int(own_len), int(t_out), int(spill), peaks))
         return float(peaks[0]), float(peaks[1])
 
+    # -- the same two halves, streamed (file -> GPU -> file: multi_gpu.run_rank) --------------------------------
+    def wav_shard_open(self, in_format: int, channels: int, t_in: int, own_len: int, t_out: int, spill: int = 0, seam=None):
+        with self.lock:
+            _lib.check(self._lib.upx_wav_shard_open(self.handle, seam.handle if seam is not None else None, int(in_format),
+                                                    int(channels), int(t_in), int(own_len), int(t_out), int(spill)))
+
+    def wav_shard_feed(self, pcm: np.ndarray, n_frames: int) -> None:
+        """The next n_frames of the shard's raw samples (uint8 view; must stay alive and unchanged until wav_shard_seal)."""
+        with self.lock:
+            _lib.check(self._lib.upx_wav_shard_feed(self.handle, pcm.ctypes.data_as(C.c_void_p), int(n_frames)))
+
+    def wav_shard_seal(self):
+        peaks = (C.c_double * 2)()
+        with self.lock:
+            _lib.check(self._lib.upx_wav_shard_seal(self.handle, peaks))
+        return float(peaks[0]), float(peaks[1])
+
+    def wav_shard_finish_async(self, scale: float, mode: str, out_format: int, n_frames: int, piece_frames: int = 1 << 22):
+        """Queues scale + export + quantisation + download piece by piece; -> ({name: uint8 payload}, n_pieces,
+        frames per piece).  Piece k of every payload is valid after wav_shard_wait_piece(k)."""
+        if mode not in self._MODES:
+            raise ValueError(f"unknown export mode {mode!r}")
+        code, names = self._MODES[mode]
+        width = 4 if out_format == _lib.F32 else out_format // 8
+        outs = [self.host_empty(n_frames * 2 * width) for _ in names]
+        ptrs = [o.ctypes.data_as(C.c_void_p) for o in outs] + [None] * (3 - len(outs))
+        n_pieces = C.c_int32()
+        with self.lock:
+            _lib.check(self._lib.upx_wav_shard_finish_async(self.handle, float(scale), code, int(out_format), ptrs[0], ptrs[1],
+                                                            ptrs[2], max(1, int(piece_frames)), C.byref(n_pieces)))
+        per = max(1, min(int(piece_frames), n_frames))
+        assert n_pieces.value == -(-n_frames // per)
+        return dict(zip(names, outs)), n_pieces.value, per
+
+    def wav_shard_wait_piece(self, piece: int) -> None:
+        _lib.check(self._lib.upx_wav_shard_wait_piece(self.handle, int(piece)))
+
     def wav_shard_planes(self):
         """Device pointers (center, left, right) of the open shard's planes, for a seam applied by the caller."""
         ptrs = [C.c_void_p() for _ in range(3)]
@@ -285,7 +322,19 @@ class DevicePlan:
     def wav_pipeline_times_ms(self):
         ms = np.zeros(3, dtype=np.float32)
         _lib.check(self._lib.upx_wav_pipeline_times_ms(self.handle, _f32p(ms)))
-        return {"h2d": float(ms[0]), "device": float(ms[1]), "d2h": float(ms[2])}
+        # begin = upload || decode || bands || peaks; begin_tail = its part after the last sample landed; finish = export || download
+        return {"begin": float(ms[0]), "begin_tail": float(ms[1]), "finish": float(ms[2])}
+
+    def stream_state(self, clear: bool = False):
+        """(accumC, accumL, accumR) of the one-band streaming ring in natural order (upx_stream_state); clear = flush."""
+        n = self.block_sizes[0]
+        acc = [np.empty(n, dtype=np.float32) for _ in range(3)]
+        _lib.check(self._lib.upx_stream_state(self.handle, *(_f32p(a) for a in acc), 1 if clear else 0))
+        return tuple(acc)
+
+    def stream_set_state(self, acc_c, acc_l, acc_r) -> None:
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (acc_c, acc_l, acc_r)]
+        _lib.check(self._lib.upx_stream_set_state(self.handle, *(_f32p(a) for a in arrs)))
 
     def seam_add_local(self, prev: Sequence[int], prev_own_len: int, nxt: Sequence[int], spill: int) -> None:
         _lib.check(self._lib.upx_seam_add_local(self.handle, *(C.c_void_p(p) for p in prev), int(prev_own_len),
@@ -333,22 +382,41 @@ class MultiBandExtractorAccu:
         self.xover_width_low_hz = xover_width_low_hz
         self.xover_width_high_hz = xover_width_high_hz
         self.device = device
-        # streaming state for process_stereo_chunk / flush_final (:269-271)
-        self.accumC = np.zeros(block_size, dtype=np.float32)
-        self.accumL = np.zeros(block_size, dtype=np.float32)
-        self.accumR = np.zeros(block_size, dtype=np.float32)
+        # streaming state for process_stereo_chunk / flush_final (:269-271): the three accumulators live on the device
+        # once the first block has gone through (upx_stream_chunk); .accumC / .accumL / .accumR read them back
+        self._accum = [np.zeros(block_size, dtype=np.float32) for _ in range(3)]
         self._plan: Optional[DevicePlan] = None
-        self._chunk_state = None   # device buffers + staging of process_stereo_chunk
+        self._streaming = False    # the accumulators are on the device
 
     def close(self) -> None:
-        """Release the device state this extractor owns (its one-band plan and the streaming buffers)."""
+        """Release the device state this extractor owns (its one-band plan with the streaming ring)."""
         plan, self._plan = self._plan, None
-        state, self._chunk_state = self._chunk_state, None
         if plan is not None and plan.handle:
-            if state is not None:
-                for b in state[0]:
-                    plan.free(b)
+            if self._streaming:
+                try:
+                    self._accum = list(plan.stream_state(clear=False))
+                except Exception:
+                    pass
             plan.close()
+        self._streaming = False
+
+    # the reference's accumulator attributes (:269-271): host arrays until streaming starts, then read from the device
+    def _accum_get(self, k: int) -> np.ndarray:
+        if self._streaming and self._plan is not None:
+            return self._plan.stream_state(clear=False)[k]
+        return self._accum[k]
+
+    def _accum_set(self, k: int, value) -> None:
+        cur = [self._accum_get(i) for i in range(3)]
+        cur[k] = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float32), (self.block_size,)))
+        if self._streaming and self._plan is not None:
+            self._plan.stream_set_state(*cur)
+        else:
+            self._accum = [np.array(c, dtype=np.float32, copy=True) for c in cur]
+
+    accumC = property(lambda self: self._accum_get(0), lambda self, v: self._accum_set(0, v))
+    accumL = property(lambda self: self._accum_get(1), lambda self, v: self._accum_set(1, v))
+    accumR = property(lambda self: self._accum_get(2), lambda self, v: self._accum_set(2, v))
 
     def __del__(self):
         try:
@@ -373,38 +441,32 @@ class MultiBandExtractorAccu:
 
     def process_stereo_chunk(self, blkL: np.ndarray, blkR: np.ndarray) -> tuple:
         """
-        One block in, first hop_size samples of the running overlap-add out
-        (center_extraction.py:353-409).  The frame transform runs on the GPU as a
-        one-frame job; the float32 accumulate / emit / shift is the reference's.
+        One block in, first hop_size samples of the running overlap-add out (center_extraction.py:353-409), in ONE
+        library call (upx_stream_chunk): the block goes up (2 N floats), the frame is transformed on the GPU, added onto
+        the overlap-add ring that stays on the device, and the emitted hop comes down (3 hop floats).  The float32
+        accumulate / emit / shift is the reference's, addition for addition.
         """
         n, hop = self.block_size, self.hop_size
         plan = self._device_plan()
+        l = np.ascontiguousarray(blkL, dtype=np.float32)
+        r = np.ascontiguousarray(blkR, dtype=np.float32)
+        outs = [np.empty(hop, dtype=np.float32) for _ in range(3)]
         with plan.lock:
-            if self._chunk_state is None:
-                # one frame in, three frames out: device buffers and host staging arrays live as long as the extractor
-                # (round 1 allocated and freed four device buffers per frame)
-                self._chunk_state = ([plan.alloc(n * 8)] + [plan.alloc(n * 4) for _ in range(3)],
-                                     np.zeros((n, 2), dtype=np.float32), [np.empty(n, dtype=np.float32) for _ in range(3)])
-            bufs, blk, recs = self._chunk_state
-            blk[:] = 0
-            blk[:len(blkL), 0] = blkL
-            blk[:len(blkR), 1] = blkR
-            plan.h2d(bufs[0], blk)
-            plan.process_device(bufs[0], n, 1, bufs[1], bufs[2], bufs[3], n)   # own_len = 1: only frame 0 exists
-            for r, b in zip(recs, bufs[1:]):
-                plan.d2h(r, b)
-        outs = []
-        for acc, rec in zip((self.accumC, self.accumL, self.accumR), recs):
-            acc += rec
-            outs.append(acc[:hop].copy())
-            acc[:-hop] = acc[hop:]
-            acc[-hop:] = 0
+            if not self._streaming:
+                if any(a.any() for a in self._accum):
+                    plan.stream_set_state(*self._accum)       # accumulators a caller filled before the first block
+                self._streaming = True
+            _lib.check(plan._lib.upx_stream_chunk(plan.handle, _f32p(l), min(len(l), n), _f32p(r), min(len(r), n),
+                                                  *(_f32p(o) for o in outs)))
         return tuple(outs)
 
     def flush_final(self) -> tuple:
         """Remaining overlap-add tail; resets the accumulators.  center_extraction.py:411-424"""
-        outs = tuple(a.copy() for a in (self.accumC, self.accumL, self.accumR))
-        for a in (self.accumC, self.accumL, self.accumR):
+        if self._streaming and self._plan is not None:
+            with self._plan.lock:
+                return self._plan.stream_state(clear=True)
+        outs = tuple(a.copy() for a in self._accum)
+        for a in self._accum:
             a[:] = 0
         return outs
 

@@ -23,6 +23,7 @@ import math
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Optional
 
 import numpy as np
@@ -32,6 +33,14 @@ from .plan import WINDOW_FUNCS
 from .rendezvous import Rendezvous
 
 _SUBTYPE_KIND = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32, "FLOAT": 1032}
+PIECE_FRAMES = 1 << 22      # frames per piece of the streamed file -> GPU -> file flow (25 MB at 24 bit stereo)
+IO_THREADS = 4              # file reads / writes in flight (os.preadv / os.pwrite release the GIL)
+
+
+def _pwrite_all(fd: int, payload, offset: int) -> None:
+    view, done = memoryview(payload).cast("B"), 0
+    while done < len(view):
+        done += os.pwrite(fd, view[done:], offset + done)
 
 
 class _Solo:
@@ -101,16 +110,32 @@ def run_rank(in_path: str, out_dir: str, export_mode: str, bands, overlap: float
             if world > 1:
                 seam = sharding.RcclSeam(plan, rank, world, broadcast=group.broadcast_bytes)
         spill = geo.spill if world > 1 else 0
+        pieces = None
         if on_device:
-            # raw bytes of the shard -> page-locked memory -> GPU; nothing is decoded on the host
+            # raw bytes of the shard -> page-locked memory -> GPU, piece by piece: a piece is fed to the device (upload,
+            # and the kernels of every chunk it completes) while the next ones are still being read from the file;
+            # nothing is decoded on the host
             block = meta["bits"] // 8 * channels
-            raw = wav.read_raw_range(in_path, shard.start, shard.t_in, meta, out=plan.host_empty(shard.t_in * block))
-            lap("read_s")
             t_out = shard.own_len + (0 if shard.last else spill)
-            peaks = plan.wav_shard_begin(raw, kind, channels, shard.t_in, shard.own_len, t_out, spill, seam)
+            raw = plan.host_empty(shard.t_in * block)
+            plan.wav_shard_open(kind, channels, shard.t_in, shard.own_len, t_out, spill, seam)
+            with ThreadPoolExecutor(max_workers=IO_THREADS) as pool:
+                futs = [pool.submit(wav.read_raw_range, in_path, shard.start + a, min(PIECE_FRAMES, shard.t_in - a), meta,
+                                    raw[a * block:(a + min(PIECE_FRAMES, shard.t_in - a)) * block])
+                        for a in range(0, shard.t_in, PIECE_FRAMES)]
+                for a, fut in zip(range(0, shard.t_in, PIECE_FRAMES), futs):
+                    n = min(PIECE_FRAMES, shard.t_in - a)
+                    if fut.result().size != n * block:
+                        raise ValueError(f"{in_path}: file ends inside the sample data")
+                    plan.wav_shard_feed(raw[a * block:(a + n) * block], n)          # in file order
+            lap("read_s")
+            peaks = plan.wav_shard_seal()
             lap("device_begin_s")
             peak_in, overall_peak, scale_factor = _global_scale(*group.allreduce_max(peaks))
-            payloads = plan.wav_shard_finish(float(scale_factor), export_mode, _SUBTYPE_KIND[subtype], shard.own_len)
+            # everything of the second half is queued; piece k of the payloads is complete after wav_shard_wait_piece(k)
+            payloads, n_pieces, per = plan.wav_shard_finish_async(float(scale_factor), export_mode, _SUBTYPE_KIND[subtype],
+                                                                  shard.own_len, PIECE_FRAMES)
+            pieces = (n_pieces, per)
             lap("device_finish_s")
         else:
             local = wav.read_range(in_path, shard.start, shard.t_in, meta)     # own range + right halo, nothing else
@@ -151,10 +176,32 @@ def run_rank(in_path: str, out_dir: str, export_mode: str, bands, overlap: float
         group.all_ok(not err, err)
         written = {}
         _, bits = wav.subtype_layout(subtype)
-        for key, payload in payloads.items():
-            path = os.path.join(out_dir, names[key])
-            wav.write_at(path, wav.info(path)["data_offset"] + shard.start * (2 * bits // 8), payload)
-            written[key] = path
+        frame = 2 * bits // 8
+        if pieces is None:
+            for key, payload in payloads.items():
+                path = os.path.join(out_dir, names[key])
+                wav.write_at(path, wav.info(path)["data_offset"] + shard.start * frame, payload)
+                written[key] = path
+        else:
+            # a piece is written (a few threads: os.pwrite releases the GIL) as soon as it has come down, while the
+            # later pieces are still being exported and downloaded
+            n_pieces, per = pieces
+            offsets = {key: wav.info(os.path.join(out_dir, names[key]))["data_offset"] + shard.start * frame for key in payloads}
+            fds = {key: os.open(os.path.join(out_dir, names[key]), os.O_WRONLY) for key in payloads}
+            try:
+                with ThreadPoolExecutor(max_workers=IO_THREADS) as pool:
+                    jobs = []
+                    for k in range(n_pieces):
+                        plan.wav_shard_wait_piece(k)
+                        a, b = k * per * frame, min(shard.own_len, (k + 1) * per) * frame
+                        for key, payload in payloads.items():
+                            jobs.append(pool.submit(_pwrite_all, fds[key], payload[a:b], offsets[key] + a))
+                    for j in jobs:
+                        j.result()
+            finally:
+                for fd in fds.values():
+                    os.close(fd)
+            written = {key: os.path.join(out_dir, names[key]) for key in payloads}
         lap("write_s")
         group.barrier()
         if rank == 0:
