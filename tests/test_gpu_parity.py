@@ -950,7 +950,8 @@ def test_baseline_plans_select_the_budgeted_kernels(ux):
     assert seen == known, known - seen                            # and the list holds nothing no plan selects
 
 
-def test_wav_pipeline_chunked_overlap_equals_single_chunk(ux, monkeypatch):
+@pytest.mark.parametrize("total", [400_000, 300_000])     # 300 000: the last chunk (5088 frames) is shorter than the spill
+def test_wav_pipeline_chunked_overlap_equals_single_chunk(ux, monkeypatch, total):
     """Round 4: upx_wav_shard_begin / _finish run the shard chunk by chunk (chunk c's kernels under the upload of chunk
     c + 1, export pieces under the download of the previous piece).  With a small UPX_WAV_CHUNK the same file goes through
     12 chunks: payload, peaks and scale equal the one-chunk pipeline's except <= 1 LSB behind chunk seams (the float32
@@ -958,7 +959,6 @@ def test_wav_pipeline_chunked_overlap_equals_single_chunk(ux, monkeypatch):
     file, and the sharded form with a caller-applied seam."""
     from upmix_amd import _lib
     rng = np.random.default_rng(41)
-    total = 400_000
     x = np.clip(0.2 * rng.standard_normal((total, 2)), -0.99, 0.99)
     pcm16 = np.rint(x * 32767).astype("<i2")
     f32 = x.astype(np.float32)

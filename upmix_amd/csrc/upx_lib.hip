@@ -144,9 +144,10 @@ __global__ void upx_export_kernel(const float* c, const float* l, const float* r
 }
 
 // seam[row][plane][spill] <- planes[own_len + i]; other rows zero (done by memset)
+// (`count` <= spill samples exist behind own_len; the row pitch stays `spill`)
 __global__ void upx_seam_pack_kernel(float* seam_row, const float* c, const float* l, const float* r,
-                                     long long own_len, long long spill) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < spill; i += (long long)gridDim.x * blockDim.x) {
+                                     long long own_len, long long spill, long long count) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
         seam_row[i] = c[own_len + i];
         seam_row[spill + i] = l[own_len + i];
         seam_row[2 * spill + i] = r[own_len + i];
@@ -287,6 +288,7 @@ struct upx_plan {
     int knob_zoom_a_age = 8;                // UPX_ZOOM_A_AGE: % by which each later dispatch round of the band-limited analysis runs slower (0 = equal shares)
     int knob_zoom_edge_percent = 76;        // UPX_ZOOM_EDGE_PERCENT: length of the first / last synthesis stream of a signal (100 = like the others)
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
+    int knob_first_band = -1;               // UPX_FIRST_BAND: launch this band's group first (-1: list order, the reference's sum order)
     int knob_min_stream_frames = 4;         // UPX_MIN_STREAM_FRAMES: shortest stream of a fused launch that does not fill the chip (>= K, even)
     int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
     float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
@@ -487,6 +489,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_PRIO_YOUNG")) p->knob_prio_young = std::atoi(e);
     if (const char* e = std::getenv("UPX_MIN_STREAM_FRAMES")) p->knob_min_stream_frames = std::atoi(e);
     if (const char* e = std::getenv("UPX_WAV_CHUNK")) p->knob_wav_chunk = std::atoll(e);
+    if (const char* e = std::getenv("UPX_FIRST_BAND")) p->knob_first_band = std::atoi(e);
     if (const char* e = std::getenv("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
     if (const char* e = std::getenv("UPX_ZOOM_C_COST")) p->knob_zoom_c_cost = std::atof(e);
     if (const char* e = std::getenv("UPX_ZOOM_EDGE_PERCENT")) p->knob_zoom_edge_percent = std::atoi(e);
@@ -837,11 +840,27 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         s.ev0 = s.ring0[slot];
         s.ev1 = s.ring1[slot];
         s.ring_used[slot] = 0;
+    }
+    // Launch order.  The first launch writes the planes, every later one reads, adds and writes them back (the band sum);
+    // list order gives the reference's float32 association ((0 + b0) + b1) + ... (center_extraction.py:508-511).
+    // UPX_FIRST_BAND = k (experiment, read at plan creation) launches the group that carries band k first: the same
+    // sum in another association (differences ~1e-8), the plane read moved from that launch to the list's first one.
+    std::vector<size_t> order;
+    {
+        const int fb = p->knob_first_band;
+        const size_t lead = fb >= 0 && fb < (int)p->bands.size() ? (size_t)p->bands[(size_t)fb].group_leader : 0;
+        if (lead != 0) order.push_back(lead);
+        for (size_t b = 0; b < p->bands.size(); ++b)
+            if (b != lead || lead == 0) order.push_back(b);
+    }
+    const size_t first_launch = order.front();
+    for (size_t b : order) {
+        BandState& s = p->bands[b];
         if (s.group_size == 0) continue;                              // carried by its group leader's launch
         const long long j_hi = (own_len + s.hop - 1) / s.hop;       // frames with j*hop < own_len
         const long long m_all = (t_out + s.hop - 1) / s.hop;        // hop-blocks that intersect [0, t_out)
         long long m_hi = j_hi + s.k - 1 < m_all ? j_hi + s.k - 1 : m_all;
-        if (b == 0) m_hi = m_all;                                   // first band initialises every output sample
+        if (b == first_launch) m_hi = m_all;                        // the first launch initialises every output sample
         if (j_hi > 0x7fffffffLL || m_all > 0x7fffffffLL) return fail(UPX_ERR_INVALID, "signal too long for int32 frame index");
         if (m_hi <= 0) continue;
         if (s.big) {
@@ -863,7 +882,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             a.t_in = (int)t_in; a.t_out = (int)t_out;
             a.hop = s.hop; a.kf = s.k;
             a.j_lo = 0; a.j_hi = (int)j_hi; a.ch = ch;
-            a.accumulate = b == 0 ? 0 : 1;
+            a.accumulate = b == first_launch ? 0 : 1;
             if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
             int n_chunks = 0;
             for (long long m0 = 0; m0 < m_hi; m0 += emit, ++n_chunks) {
@@ -996,7 +1015,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
             a.blocks_per_stream = tab_lr[1] - tab_lr[0];
             a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
-            a.accumulate = b == 0 ? 0 : 1;
+            a.accumulate = b == first_launch ? 0 : 1;
             const long long slots = (long long)p->n_cu * zoom_resident(s, true);
             if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
             const bool split = p->timing && 2 * (long long)launches.size() - 1 <= kMidEvents;
@@ -1180,7 +1199,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
         a.blocks_per_stream = (int)f;
         a.stream_m0 = uneven ? s.d_m0 : nullptr;
-        a.accumulate = b == 0 ? 0 : 1;
+        a.accumulate = b == first_launch ? 0 : 1;
         a.seam = p->d_seam;
         // one-wave workgroups that fill the machine: the first `SIMDs` of them are the older wave of their SIMD
         // (BandArgs::prio_split)
@@ -1655,7 +1674,8 @@ void wav_chunks(const upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out,
         w.start = start;
         w.own = last ? own_len - start : chunk;
         w.t_in = t_in - start < w.own + spill ? t_in - start : w.own + spill;
-        w.t_out = last ? t_out - start : w.own + spill;
+        // (the planes end at t_out: a chunk next to a short last chunk must not write - or park - samples beyond them)
+        w.t_out = last || t_out - start < w.own + spill ? t_out - start : w.own + spill;
         out.push_back(w);
     }
 }
@@ -1777,13 +1797,15 @@ int upx_wav_shard_feed(upx_plan* p, const void* pcm, int64_t n_frames) {
             return rc;
         if (c > 0) {
             const float* side = p->d_wav_side[(c - 1) & 1];
-            const int64_t add = cspill < w.t_out ? cspill : w.t_out;
+            const int64_t parked = chunks[c - 1].t_out - chunks[c - 1].own;     // <= cspill
+            const int64_t add = parked < w.t_out ? parked : w.t_out;
             hipLaunchKernelGGL(upx_seam_add_kernel, dim3(grid_for(add)), dim3(256), 0, st, d_plane[0] + w.start,
                                d_plane[1] + w.start, d_plane[2] + w.start, side, side + cspill, side + 2 * cspill, (long long)add);
         }
         if (c + 1 < chunks.size())
             hipLaunchKernelGGL(upx_seam_pack_kernel, dim3(grid_for(cspill)), dim3(256), 0, st, p->d_wav_side[c & 1],
-                               d_plane[0] + w.start, d_plane[1] + w.start, d_plane[2] + w.start, (long long)w.own, (long long)cspill);
+                               d_plane[0] + w.start, d_plane[1] + w.start, d_plane[2] + w.start, (long long)w.own, (long long)cspill,
+                               (long long)(w.t_out - w.own));
         // plane peaks of the chunk's owned range, final now - except the shard's head under a multi-rank seam
         if (p->wav_comm && c == 0) {
             p->wav_peaks_pending_head = true;
@@ -2118,7 +2140,7 @@ int seam_exchange_impl(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t 
     HIP_TRY(hipMemsetAsync(c->d_seam, 0, (size_t)total * sizeof(float), p->stream));
     if (pack)
         hipLaunchKernelGGL(upx_seam_pack_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream,
-                           c->d_seam + row * my_row, d_c, d_l, d_r, (long long)own_len, (long long)spill);
+                           c->d_seam + row * my_row, d_c, d_l, d_r, (long long)own_len, (long long)spill, (long long)spill);
     NCCL_TRY(g_rccl.AllReduce(c->d_seam, c->d_seam, (size_t)total, ncclFloat32, ncclSum, c->comm, p->stream));
     if (add_row >= 0 && add_len > 0) {
         const float* prev = c->d_seam + row * add_row;
