@@ -258,7 +258,17 @@ def e2e_rates(ux, plan, bands, sr, nominal, seed=2):
     # WAV pipeline: PCM16 in, decode + all bands + peak scale + stereo_sum layout + quantisation on the device, PCM16 out
     pcm = np.clip(np.rint(x * 32767.0), -32768, 32767).astype("<i2")
     del x
+    # (pageable source: every chunk's upload is a blocking staged copy on the calling thread, in turn with its launches)
     fn = lambda: plan.wav_pipeline(pcm, 16, 2, nominal, "stereo_sum", 16)  # noqa: E731
+    fn()
+    dt = timed(fn)
+    out["upx_wav_pipeline_pcm16_stereo_sum_pageable_input"] = {"ms": round(dt * 1e3, 2),
+                                                              "Msamples_per_s": round(nominal / dt / 1e6, 1)}
+    # ... and what the file entries do (cli, batch, multi_gpu read the file's bytes into page-locked memory): asynchronous
+    # uploads, chunk c's kernels under the upload of chunk c + 1
+    pinned = plan.host_empty(pcm.nbytes).view("<i2").reshape(pcm.shape)
+    pinned[...] = pcm
+    fn = lambda: plan.wav_pipeline(pinned, 16, 2, nominal, "stereo_sum", 16)  # noqa: E731
     fn()
     dt = timed(fn)
     t = plan.wav_pipeline_times_ms()

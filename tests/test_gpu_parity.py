@@ -1022,3 +1022,40 @@ def test_streaming_chunks_on_the_device_ring(ux, orc):
         assert np.all(l == 0.25) and not c.any()
         assert np.all(bex.accumL[:n - hop] == 0.25) and not bex.accumL[n - hop:].any()
         bex.close()
+
+
+def test_wav_pipeline_beyond_2_to_29_frames(ux):
+    """VERDICT r3 missing 4: the device codec refused files of 2^29 frames or more (configs[3] taken literally on ONE GPU is
+    691 M frames).  The shard now runs in chunks, so only a chunk has to fit a launch's 2^29 - 1 samples.  2^29 + 300 000
+    mono 16-bit frames (1.07 GB in, 2.1 GB out), silent except for a burst that straddles frame 2^29: the output is silent
+    where the input is (exact zeros), and the burst region equals the small file that holds the burst alone (the global
+    peaks - hence the scale - are the burst's in both)."""
+    from upmix_amd import _lib
+    big = (1 << 29) + 300_000
+    lo, hi = (1 << 29) - 150_000, (1 << 29) + 150_000          # burst: 300 000 frames across the old limit
+    rng = np.random.default_rng(99)
+    burst = (rng.standard_normal(hi - lo) * 4000).astype("<i2")
+    bands = ux.chain_bands([0, 30, 120, 480, 1920, 7680], 0.75, ux.make_blackman_harris, 48000, max_block_size=8192,
+                           verbose=False)
+    plan = ux.DevicePlan(bands)
+    try:
+        pcm = np.zeros(big, dtype="<i2")
+        pcm[lo:hi] = burst
+        out, stats = plan.wav_pipeline(pcm, _lib.PCM16, 1, big, "stereo_sum", _lib.PCM16)
+        got = out["Sum"].view("<i2").reshape(-1, 2)
+        assert got.shape == (big, 2)
+        assert not got[:lo - 8192].any() and not got[hi + 8192:].any()          # silence stays silence (+- one frame)
+        # the burst alone, padded so that its frames sit on the same hop grid (lo is a multiple of 2 hop_max = 4096? no:
+        # align the small file's start to the grid below lo)
+        a = (lo - 16384) // 4096 * 4096
+        small = np.zeros(hi + 16384 - a, dtype="<i2")
+        small[lo - a:hi - a] = burst
+        ref, ref_stats = plan.wav_pipeline(small, _lib.PCM16, 1, len(small), "stereo_sum", _lib.PCM16)
+        want = ref["Sum"].view("<i2").reshape(-1, 2)
+        assert abs(stats["scale_factor"] - ref_stats["scale_factor"]) <= 1e-6 * ref_stats["scale_factor"]
+        seg = got[a:a + len(small)].astype(np.int32)
+        assert np.max(np.abs(seg - want.astype(np.int32))) <= 1                 # chunk seams fall elsewhere: <= 1 LSB
+        assert np.count_nonzero(seg != want) <= 2000
+        del out, got, ref, want
+    finally:
+        plan.close()

@@ -124,7 +124,7 @@ def main(argv=None) -> int:
                         wav.device_kind(m, paths[i])
                     except ValueError:
                         return False
-                    return known_mode and not a.host_export and m["channels"] in (1, 2) and 0 < m["n_frames"] < (1 << 29)
+                    return known_mode and not a.host_export and m["channels"] in (1, 2) and m["n_frames"] > 0
 
                 def fetch(i):   # reader thread: the file's sample bytes, undecoded, into page-locked memory
                     m = metas[i]

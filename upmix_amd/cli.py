@@ -45,13 +45,14 @@ def run(in_filename: str = "eyes.wav", export_mode: str = "stereo_sum", in_dir: 
     custom_io = reader is not wav.read or writer is not wav.write
     if not host_export and not custom_io and export_mode in export.EXPORT_MODES:
         try:
-            raw, kind, channels, sr, n_frames = wav.read_raw(in_path)
+            meta = wav.info(in_path)
+            kind = wav.device_kind(meta, in_path)
         except ValueError:
-            raw = None
-        if raw is not None and channels in (1, 2) and 0 < n_frames < (1 << 29):
-            return _run_device_codec(raw, kind, channels, sr, n_frames, in_path, base_in_name, export_mode, out_dir,
-                                     band_edges, overlap, window, xover_mode, max_stft, threshold_factor, xo_fraction,
-                                     device, subtype)
+            meta = None
+        if meta is not None and meta["channels"] in (1, 2) and meta["n_frames"] > 0:
+            return _run_device_codec(meta, kind, int(meta["channels"]), int(meta["rate"]), int(meta["n_frames"]), in_path,
+                                     base_in_name, export_mode, out_dir, band_edges, overlap, window, xover_mode, max_stft,
+                                     threshold_factor, xo_fraction, device, subtype)
     wave, sr = reader(in_path)
     print(f"Loaded '{in_path}', sr={sr}, shape={wave.shape}")
     if wave.ndim == 1:
@@ -91,9 +92,10 @@ def run(in_filename: str = "eyes.wav", export_mode: str = "stereo_sum", in_dir: 
 _SUBTYPE_KIND = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32, "FLOAT": 1032}
 
 
-def _run_device_codec(raw, kind, channels, sr, n_frames, in_path, base_in_name, export_mode, out_dir, band_edges,
+def _run_device_codec(meta, kind, channels, sr, n_frames, in_path, base_in_name, export_mode, out_dir, band_edges,
                       overlap, window, xover_mode, max_stft, threshold_factor, xo_fraction, device, subtype):
-    """Same flow with decode, peak scale, export layout and quantisation on the GPU (upx_wav_pipeline)."""
+    """Same flow with decode, peak scale, export layout and quantisation on the GPU (upx_wav_pipeline); the file's sample
+    bytes are read, undecoded, straight into page-locked memory, so the chunks' uploads run beside their kernels."""
     from .extractor import DevicePlan
     print(f"Loaded '{in_path}', sr={sr}, shape={(n_frames, channels) if channels > 1 else (n_frames,)}")
     band_extractors = chain_bands(list(band_edges), overlap, WINDOW_FUNCS[window], sr, xover_mode,
@@ -101,6 +103,8 @@ def _run_device_codec(raw, kind, channels, sr, n_frames, in_path, base_in_name, 
                                   xo_fraction=xo_fraction, device=device)
     plan = DevicePlan(band_extractors, device)
     try:
+        block = meta["bits"] // 8 * channels
+        raw = wav.read_raw_range(in_path, 0, n_frames, meta, out=plan.host_empty(n_frames * block))
         payloads, stats = plan.wav_pipeline(raw, kind, channels, n_frames, export_mode, _SUBTYPE_KIND[subtype])
     finally:
         plan.close()

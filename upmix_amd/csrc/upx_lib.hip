@@ -1692,9 +1692,13 @@ int upx_wav_shard_open(upx_plan* p, upx_comm* comm, int in_format, int channels,
     if (!p || t_in < 1 || own_len < 1 || own_len > t_in || t_out < own_len || spill < 0 || (channels != 1 && channels != 2))
         return fail(UPX_ERR_INVALID, "upx_wav_shard_open: bad argument");
     if (!wav_format_ok(in_format)) return fail(UPX_ERR_INVALID, "upx_wav_shard_open: unknown sample format");
-    if (t_in >= (1LL << 29) || t_out >= (1LL << 29))
-        return fail(UPX_ERR_INVALID, "upx_wav_shard_open: at most 2^29-1 frames per shard");
     if (comm && comm->plan != p) return fail(UPX_ERR_INVALID, "upx_wav_shard_open: the communicator belongs to another plan");
+    // a launch indexes at most 2^29 - 1 samples: longer shards must be cut into chunks (every plan whose hops share a grid)
+    wav_chunks(p, t_in, own_len, t_out, p->wav_chunk_list);
+    for (const auto& w : p->wav_chunk_list)
+        if (w.t_in >= (1LL << 29) || w.t_out >= (1LL << 29))
+            return fail(UPX_ERR_INVALID, "upx_wav_shard_open: a shard of 2^29 frames or more needs UPX_WAV_CHUNK > 0 and hops that "
+                                         "share a shard grid");
     const bool exchange = comm && comm->n_ranks > 1 && spill > 0;
     if (exchange && comm->rank + 1 < comm->n_ranks && t_out < own_len + spill)
         return fail(UPX_ERR_INVALID, "upx_wav_shard_open: planes of a shard with a successor need own_len + spill samples");
@@ -1716,7 +1720,6 @@ int upx_wav_shard_open(upx_plan* p, upx_comm* comm, int in_format, int channels,
     // upx_process (run_items) on planes that stay resident, because the one scale of main.py:85-97 needs every peak
     // before anything can be exported.  The peaks are folded into the same stream (max of bit patterns, one
     // download of four words at the end).
-    wav_chunks(p, t_in, own_len, t_out, p->wav_chunk_list);
     p->wav_cspill = 0;
     int64_t cgrid = 0;
     if (p->wav_chunk_list.size() > 1) (void)shard_geometry(p, &cgrid, &p->wav_cspill);
@@ -1978,7 +1981,6 @@ int upx_wav_pipeline(upx_plan* p, const void* pcm_in, int in_format, int channel
         if (!outs[i]) return fail(UPX_ERR_INVALID, "upx_wav_pipeline: output buffer %d is NULL", i);
     stats[0] = 1e-9; stats[1] = 1e-9; stats[2] = 1.0;
     if (n == 0) return UPX_OK;
-    if (n >= (1LL << 29)) return fail(UPX_ERR_INVALID, "upx_wav_pipeline: at most 2^29-1 frames per call");
     // one shard that is the whole file: the two halves of the sharded pipeline with the scale of this file alone
     double peaks[2];
     if (int rc = upx_wav_shard_begin(p, nullptr, pcm_in, in_format, channels, n, n, n, 0, peaks)) return rc;
