@@ -444,6 +444,7 @@ def main():
     # idling).  The metric is sustained throughput, so the ramp is run down before the W warm-up steps, untimed, and
     # reported in the line (`preheat`); --preheat-ms 0 switches it off.
     preheat_steps = 0
+    cold_ms = None
     if args.preheat_ms > 0:
         t_pre = time.perf_counter()
         for _ in range(5):
@@ -451,6 +452,7 @@ def main():
         plan.sync()
         # every rank runs the same number of steps (a step of the sharded path ends in a collective)
         per_step_ms = group.allreduce_max([(time.perf_counter() - t_pre) * 1e3 / 5])[0]
+        cold_ms = per_step_ms      # what a caller's first calls on an idle card cost (clock ramp, first-touch of the tables)
         preheat_steps = max(5, min(2000, int(np.ceil(args.preheat_ms / max(per_step_ms, 1e-3)))))
         for _ in range(preheat_steps - 5):
             step()
@@ -550,6 +552,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "preheat": {"untimed_steps": preheat_steps, "ms": args.preheat_ms,
+                        "first_5_steps_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
                         "why": "an idle card reaches its running clocks after ~20 steps; run before the warm-up steps, "
                                "never inside the timed region (scripts/clock_ramp_check.py, DESIGN.md 5)"},
             "kernel_timing": {"steps_with_events": timed_steps, "stride": TIMING_STRIDE,

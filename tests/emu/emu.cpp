@@ -282,6 +282,17 @@ extern "C" int emu_big_band(int log2n, int hop, const float* in, long long t_in,
 // ---- hand-over logic of the streamed host calls (upx_pipeline.h) with injected failures ----------
 // submit / complete sleep `*_us` microseconds; item `fail_submit` / `fail_complete` (-1: none) returns -3.
 // Reports how many items each side finished.  A regression of the round-1 hang shows up as a test timeout.
+// upx::wav_schedule (upx_pipeline.h): -> number of chunks; the first `cap` of them as rows (start, own, t_in, t_out)
+extern "C" int emu_wav_schedule(long long t_in, long long own_len, long long t_out, long long grid, long long spill, long long chunk,
+                                int uniform, int bytes_per_frame, double rate, long long* rows, int cap) {
+    std::vector<upx::WavChunkRec> v;
+    upx::wav_schedule(t_in, own_len, t_out, grid, spill, chunk, uniform != 0, bytes_per_frame, rate, v);
+    for (size_t i = 0; i < v.size() && (int)i < cap; ++i) {
+        rows[4 * i] = v[i].start; rows[4 * i + 1] = v[i].own; rows[4 * i + 2] = v[i].t_in; rows[4 * i + 3] = v[i].t_out;
+    }
+    return (int)v.size();
+}
+
 extern "C" int emu_pipeline(long long n_items, long long fail_submit, long long fail_complete, int submit_us,
                             int complete_us, long long* n_submitted, long long* n_completed, char* msg, int msg_len) {
     std::atomic<long long> subs{0}, comps{0};

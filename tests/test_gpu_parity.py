@@ -950,11 +950,11 @@ def test_baseline_plans_select_the_budgeted_kernels(ux):
     assert seen == known, known - seen                            # and the list holds nothing no plan selects
 
 
-@pytest.mark.parametrize("total", [400_000, 300_000])     # 300 000: the last chunk (5088 frames) is shorter than the spill
-def test_wav_pipeline_chunked_overlap_equals_single_chunk(ux, monkeypatch, total):
+@pytest.mark.parametrize("total,uniform", [(400_000, 1), (300_000, 1), (400_000, 0)])
+def test_wav_pipeline_chunked_overlap_equals_single_chunk(ux, monkeypatch, total, uniform):
     """Round 4: upx_wav_shard_begin / _finish run the shard chunk by chunk (chunk c's kernels under the upload of chunk
     c + 1, export pieces under the download of the previous piece).  With a small UPX_WAV_CHUNK the same file goes through
-    12 chunks: payload, peaks and scale equal the one-chunk pipeline's except <= 1 LSB behind chunk seams (the float32
+    9-12 chunks of equal length (UPX_WAV_UNIFORM=1) or 5 that shrink geometrically (the default geometry): payload, peaks and scale equal the one-chunk pipeline's except <= 1 LSB behind chunk seams (the float32
     association of the overlap-add there, as between the chunks of upx_process_chunked); every mode and codec, a mono
     file, and the sharded form with a caller-applied seam."""
     from upmix_amd import _lib
@@ -967,6 +967,7 @@ def test_wav_pipeline_chunked_overlap_equals_single_chunk(ux, monkeypatch, total
     monkeypatch.setenv("UPX_WAV_CHUNK", "0")
     whole = ux.DevicePlan(bands)
     monkeypatch.setenv("UPX_WAV_CHUNK", "32768")          # >= 4 x spill (6144), a multiple of the grid (4096)
+    monkeypatch.setenv("UPX_WAV_UNIFORM", str(uniform))
     cut = ux.DevicePlan(bands)
     try:
         for src, in_kind, ch in ((pcm16, _lib.PCM16, 2), (f32, _lib.F32, 2), (pcm16[:, 0].copy(), _lib.PCM16, 1)):

@@ -315,6 +315,7 @@ def test_streamed_file_to_file_in_pieces(tmp_path, monkeypatch):
         monkeypatch.setattr(multi_gpu, "PIECE_FRAMES", 1 << 22)
         assert multi_gpu.main(args(os.path.join(tmp, "one"), mode, sub)) == 0
         monkeypatch.setenv("UPX_WAV_CHUNK", "32768")
+        monkeypatch.setenv("UPX_WAV_UNIFORM", "1")
         monkeypatch.setattr(multi_gpu, "PIECE_FRAMES", 50000)
         assert multi_gpu.main(args(os.path.join(tmp, "cut"), mode, sub)) == 0
         names = sorted(os.listdir(os.path.join(tmp, "one")))

@@ -64,18 +64,45 @@ __global__ void upx_zoom_seam_add_kernel(upx::ZoomArgs a, int n_lr, int n_c, int
 }
 
 // max |x| as a bit pattern: non-negative floats order like their bit patterns, and a NaN (sign cleared) lies above
-// every number, so a NaN anywhere gives NaN - what np.max(np.abs(.)) gives main.py:53, :85-88
-__global__ void upx_absmax_kernel(const float* x, long long n, unsigned int* result) {
+// every number, so a NaN anywhere gives NaN - what np.max(np.abs(.)) gives main.py:53, :85-88.
+// One atomic per WORKGROUP (round 3 issued one per wave: 8192 atomics on one address serialise in the L2 - 100 us for a
+// pass that reads 64 MB - which the chunked WAV pipeline of round 4 pays twelve times per file), 16-byte loads.
+__device__ __forceinline__ void upx_absmax_body(const float* x, long long n, unsigned int* result);
+__global__ void upx_absmax_kernel(const float* x, long long n, unsigned int* result) { upx_absmax_body(x, n, result); }
+// the three planes of a chunk in one launch (blockIdx.y = plane; results in result[0..2])
+__global__ void upx_absmax3_kernel(const float* c, const float* l, const float* r, long long n, unsigned int* result) {
+    upx_absmax_body(blockIdx.y == 0 ? c : (blockIdx.y == 1 ? l : r), n, result + blockIdx.y);
+}
+__device__ __forceinline__ void upx_absmax_body(const float* x, long long n, unsigned int* result) {
+    __shared__ unsigned int part[4];
     unsigned int m = 0u;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned int b = __float_as_uint(x[i]) & 0x7fffffffu;
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    // head up to the first 16-byte boundary, body in float4, tail
+    long long head = (long long)(((16u - (unsigned)((size_t)x & 15u)) & 15u) / 4u);
+    if (head > n) head = n;
+    const long long n4 = (n - head) / 4;
+    const uint4* x4 = reinterpret_cast<const uint4*>(x + head);
+    for (long long i = tid; i < n4; i += stride) {
+        const uint4 v = x4[i];
+        const unsigned int a = v.x & 0x7fffffffu, b = v.y & 0x7fffffffu, c = v.z & 0x7fffffffu, d = v.w & 0x7fffffffu;
+        const unsigned int ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+        m = q > m ? q : m;
+    }
+    for (long long i = tid; i < head + (n - head - 4 * n4); i += stride) {
+        const long long j = i < head ? i : head + 4 * n4 + (i - head);
+        const unsigned int b = __float_as_uint(x[j]) & 0x7fffffffu;
         m = b > m ? b : m;
     }
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned int q = (unsigned int)__shfl_xor((int)m, o);
         m = q > m ? q : m;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(result, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = part[w] > m ? part[w] : m;
+        if (m) atomicMax(result, m);
+    }
 }
 
 __global__ void upx_scale_kernel(float* x, long long n, float s) {
@@ -314,6 +341,8 @@ struct upx_plan {
     // chunked WAV pipeline: owned frames per chunk (UPX_WAV_CHUNK, 0 = one chunk), per-chunk events, the spill of a chunk
     // parked while the next chunk's kernels overwrite that range, peaks (input, C, Ls, Rs) as bit patterns
     long long knob_wav_chunk = 1LL << 22;
+    double knob_wav_kernel_rate = 21.0;     // UPX_WAV_KERNEL_RATE: M frames per ms the plan's kernels are assumed to sustain (chunk schedule)
+    int knob_wav_uniform = 0;               // UPX_WAV_UNIFORM=1: chunks of equal length (tests: many seams; A/B of the geometry)
     std::vector<hipEvent_t> wav_piece_ev, wav_down_ev;
     float* d_wav_side[2] = {nullptr, nullptr};
     size_t wav_side_floats = 0;
@@ -321,9 +350,8 @@ struct upx_plan {
     bool wav_peaks_pending_head = false;    // multi-rank: chunk 0's plane peaks wait for the RCCL seam
     int64_t wav_head_own = 0;
     // between upx_wav_shard_open and _seal: the chunk list, frames fed / decoded, the next chunk to run
-    struct WavChunkRec { int64_t start, own, t_in, t_out; };
     bool wav_feeding = false;
-    std::vector<WavChunkRec> wav_chunk_list;
+    std::vector<upx::WavChunkRec> wav_chunk_list;
     int64_t wav_fed = 0, wav_decoded = 0, wav_spill = 0, wav_cspill = 0;
     int wav_next_chunk = 0, wav_n_feed = 0;
     upx_comm* wav_comm = nullptr;
@@ -424,6 +452,11 @@ long long max_auto_streams(const upx_plan* p, const BandState& s) {
     return (long long)p->n_cu * resident * s.kern->g;
 }
 
+// a reduction to one word: enough blocks to fill the chip twice, one atomic each
+int grid_reduce(long long n) {
+    long long g = (n / 4 + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
 int grid_for(long long n) {
     long long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -490,6 +523,8 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_MIN_STREAM_FRAMES")) p->knob_min_stream_frames = std::atoi(e);
     if (const char* e = std::getenv("UPX_WAV_CHUNK")) p->knob_wav_chunk = std::atoll(e);
     if (const char* e = std::getenv("UPX_FIRST_BAND")) p->knob_first_band = std::atoi(e);
+    if (const char* e = std::getenv("UPX_WAV_UNIFORM")) p->knob_wav_uniform = std::atoi(e);
+    if (const char* e = std::getenv("UPX_WAV_KERNEL_RATE")) p->knob_wav_kernel_rate = std::atof(e);
     if (const char* e = std::getenv("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
     if (const char* e = std::getenv("UPX_ZOOM_C_COST")) p->knob_zoom_c_cost = std::atof(e);
     if (const char* e = std::getenv("UPX_ZOOM_EDGE_PERCENT")) p->knob_zoom_edge_percent = std::atoi(e);
@@ -1600,7 +1635,7 @@ int upx_absmax(upx_plan* p, const float* d_x, int64_t n, float* result) {
     if (!p || !result || n < 0) return fail(UPX_ERR_INVALID, "upx_absmax: bad argument");
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemsetAsync(p->d_scalar, 0, sizeof(unsigned int), p->stream));
-    if (n > 0) hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_for(n)), dim3(256), 0, p->stream, d_x, (long long)n, p->d_scalar);
+    if (n > 0) hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_reduce(n)), dim3(256), 0, p->stream, d_x, (long long)n, p->d_scalar);
     unsigned int bits = 0;
     HIP_TRY(hipMemcpyAsync(&bits, p->d_scalar, sizeof bits, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1649,35 +1684,14 @@ int ensure_copy_streams(upx_plan* p) {
 namespace {
 // One chunk of the WAV pipeline: owned frames [start, start + own) of the shard; its kernels read t_in frames from
 // `start` (own range + right halo) and write t_out (own + spill; the shard's last chunk: what is left of the planes).
-using WavChunk = upx_plan::WavChunkRec;
+using WavChunk = upx::WavChunkRec;
 
-// Chunks of `chunk` owned frames on the shard grid (as items_of_track cuts a streamed host call): the kernels of chunk c
-// run while the samples of chunk c + 1 come up.  One chunk when the plan's hops share no grid or the shard is short.
-void wav_chunks(const upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out, std::vector<WavChunk>& out) {
-    out.clear();
+// the chunk schedule of a shard (upx::wav_schedule, upx_pipeline.h) for this plan's geometry and knobs
+void wav_chunks(const upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out, int bytes_per_frame, std::vector<WavChunk>& out) {
     int64_t grid = 0, spill = 0;
-    int64_t chunk = p->knob_wav_chunk;
-    const bool gridded = shard_geometry(p, &grid, &spill);
-    if (chunk > 0 && gridded) {
-        chunk = (chunk + grid - 1) / grid * grid;
-        if (chunk < spill) chunk = (spill + grid - 1) / grid * grid;
-    }
-    if (chunk <= 0 || !gridded || own_len < 2 * chunk || chunk < 4 * spill) {
-        out.push_back(WavChunk{0, own_len, t_in, t_out});
-        return;
-    }
-    const int64_t n = (own_len + chunk - 1) / chunk;
-    for (int64_t c = 0; c < n; ++c) {
-        const int64_t start = c * chunk;
-        const bool last = c == n - 1;
-        WavChunk w;
-        w.start = start;
-        w.own = last ? own_len - start : chunk;
-        w.t_in = t_in - start < w.own + spill ? t_in - start : w.own + spill;
-        // (the planes end at t_out: a chunk next to a short last chunk must not write - or park - samples beyond them)
-        w.t_out = last || t_out - start < w.own + spill ? t_out - start : w.own + spill;
-        out.push_back(w);
-    }
+    if (!shard_geometry(p, &grid, &spill)) grid = 0;
+    upx::wav_schedule(t_in, own_len, t_out, grid, spill, p->knob_wav_chunk, p->knob_wav_uniform != 0, bytes_per_frame,
+                      p->knob_wav_kernel_rate, out);
 }
 
 double wall_ms() {
@@ -1694,7 +1708,7 @@ int upx_wav_shard_open(upx_plan* p, upx_comm* comm, int in_format, int channels,
     if (!wav_format_ok(in_format)) return fail(UPX_ERR_INVALID, "upx_wav_shard_open: unknown sample format");
     if (comm && comm->plan != p) return fail(UPX_ERR_INVALID, "upx_wav_shard_open: the communicator belongs to another plan");
     // a launch indexes at most 2^29 - 1 samples: longer shards must be cut into chunks (every plan whose hops share a grid)
-    wav_chunks(p, t_in, own_len, t_out, p->wav_chunk_list);
+    wav_chunks(p, t_in, own_len, t_out, channels * wav_bytes_of(in_format), p->wav_chunk_list);
     for (const auto& w : p->wav_chunk_list)
         if (w.t_in >= (1LL << 29) || w.t_out >= (1LL << 29))
             return fail(UPX_ERR_INVALID, "upx_wav_shard_open: a shard of 2^29 frames or more needs UPX_WAV_CHUNK > 0 and hops that "
@@ -1790,7 +1804,7 @@ int upx_wav_shard_feed(upx_plan* p, const void* pcm, int64_t n_frames) {
                                (long long)(end - up), d_st + 2 * up);
             const int64_t owned_end = end < own_len ? end : own_len;   // input peak: owned frames only (main.py:53)
             if (owned_end > up)
-                hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_for(2 * (owned_end - up))), dim3(256), 0, st, d_st + 2 * up,
+                hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_reduce(2 * (owned_end - up))), dim3(256), 0, st, d_st + 2 * up,
                                    (long long)(2 * (owned_end - up)), p->d_wav_peaks);
             p->wav_decoded = end;
         }
@@ -1814,9 +1828,8 @@ int upx_wav_shard_feed(upx_plan* p, const void* pcm, int64_t n_frames) {
             p->wav_peaks_pending_head = true;
             p->wav_head_own = w.own;
         } else {
-            for (int k = 0; k < 3; ++k)
-                hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_for(w.own)), dim3(256), 0, st, d_plane[k] + w.start,
-                                   (long long)w.own, p->d_wav_peaks + 1 + k);
+            hipLaunchKernelGGL(upx_absmax3_kernel, dim3(grid_reduce(w.own), 3), dim3(256), 0, st, d_plane[0] + w.start,
+                               d_plane[1] + w.start, d_plane[2] + w.start, (long long)w.own, p->d_wav_peaks + 1);
         }
         p->wav_next_chunk += 1;
     }
@@ -1836,9 +1849,8 @@ int upx_wav_shard_seal(upx_plan* p, double* peaks) {
     if (p->wav_comm)
         if (int rc = upx_comm_seam_exchange(p->wav_comm, d_plane[0], d_plane[1], d_plane[2], p->wav_own, p->wav_spill)) return rc;
     if (p->wav_peaks_pending_head) {
-        for (int k = 0; k < 3; ++k)
-            hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_for(p->wav_head_own)), dim3(256), 0, st, d_plane[k],
-                               (long long)p->wav_head_own, p->d_wav_peaks + 1 + k);
+        hipLaunchKernelGGL(upx_absmax3_kernel, dim3(grid_reduce(p->wav_head_own), 3), dim3(256), 0, st, d_plane[0], d_plane[1],
+                           d_plane[2], (long long)p->wav_head_own, p->d_wav_peaks + 1);
         p->wav_peaks_pending_head = false;
     }
     p->wav_open = true;
