@@ -9,11 +9,13 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT, e.g.
 
 Every rank reads ONLY the bytes of its own time shard (+ the right halo) from the input file, straight into
 page-locked memory, and writes ONLY its own slice of every output file at that slice's byte offset (rank 0 writes
-the headers first).  Between the two, everything runs on the rank's GPU (upx_wav_shard_begin / _finish): the raw
-samples go up, are decoded, upmixed, the overlap-add seam crosses RCCL, a device max-reduce finds the shard's peaks;
-the two scalars cross the process group (upmix_amd.rendezvous: standard-library sockets - no torch in this
-process); then scale, export layout (main.py:110-157) and quantisation run on the device and only final 2-channel
-sample data comes down.  `--host-export`, files with more than two channels and sample formats the device codec does
+the headers first).  Between the two, everything runs on the rank's GPU, and since round 4 the three stages STREAM
+(upx_wav_shard_open / _feed / _seal, _finish_async / _wait_piece): a few threads read 4 M-frame pieces of the shard,
+each piece is fed to the device as soon as it is there (upload, and behind it the decode and the kernels of every
+chunk whose input is complete), the overlap-add seam crosses RCCL, the shard's peaks come out of the same stream; the
+two scalars cross the process group (upmix_amd.rendezvous: standard-library sockets - no torch in this process); then
+scale, export layout (main.py:110-157) and quantisation run piece by piece on the device, each piece of final
+2-channel sample data comes down while the next one is exported, and is written to the files the moment it has landed.  `--host-export`, files with more than two channels and sample formats the device codec does
 not read take the NumPy flow of round 2 (decode, scale and export on the host, float64 like main.py).
 """
 from __future__ import annotations
