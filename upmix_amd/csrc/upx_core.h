@@ -263,6 +263,28 @@ UPX_HD void store_nt(UPX_GLOBAL T& ref, T v) {
 #endif
 }
 
+// A value every lane of the wave holds alike, moved to a scalar register (a table entry fetched with a vector load is
+// uniform by value but lives in a VGPR, and everything computed from it - frame numbers, sample offsets, pointers - would
+// be vector arithmetic).
+UPX_HD int uniform_int(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+
+// The lane's own element offset of gat_u, pinned where it is used: hoisted out of a loop, its zero-extension becomes a
+// 64-bit loop-invariant VGPR pair in another basic block, where instruction selection no longer sees `sgpr base + zext(vgpr)`
+// and falls back to a 64-bit vector add per access instead of `global_load/store v_off, s[base:base+1]`.  Call it once per
+// phase (one v_mov), not per access.
+UPX_HD unsigned pin_lane(unsigned voff) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(UPX_GAT_U_PLAIN)
+    asm volatile("" : "+v"(voff));
+#endif
+    return voff;
+}
+
 // Element `uniform + voff` of a global array: `uniform` (elements) is the same for every lane and need not be a
 // compile-time constant (it joins the base in SGPRs), `voff` is the lane's own 32-bit element offset:
 // `global_load/store v, v_off, s[base:base+1]` without 64-bit vector arithmetic.
@@ -270,7 +292,17 @@ template <class T>
 UPX_HD UPX_GLOBAL T& gat_u(UPX_GLOBAL T* base, long long uniform, unsigned voff) {
 #if defined(__HIP_DEVICE_COMPILE__)
     UPX_GLOBAL char* b = (UPX_GLOBAL char*)(base + uniform);
+#if !defined(UPX_GAT_U_PLAIN)
+    // The uniform pointer is pinned to a scalar register pair HERE.  Without this the optimiser re-associates the
+    // address as (base + lane offset) + uniform and strength-reduces the slots of an array into a chain of 64-bit VECTOR
+    // adds (v_lshl_add_u64, one per access, each waiting for the previous one): 25-35 per transform in the band-limited
+    // synthesis' interior loop, 40 per unit in the analysis - a tenth of their vector instructions (round 4, ISA).
+    asm volatile("" : "+s"(b));
+    // (the lane's offset must come from pin_lane() in the same basic block, see there)
     return *(UPX_GLOBAL T*)(b + (size_t)(voff * (unsigned)sizeof(T)));
+#else
+    return *(UPX_GLOBAL T*)(b + (size_t)(voff * (unsigned)sizeof(T)));
+#endif
 #else
     return base[uniform + (long long)voff];
 #endif

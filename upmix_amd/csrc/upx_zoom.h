@@ -311,8 +311,8 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
 #else
         const int* tab = a.deal_tab;
 #endif
-        extra_first = rect + tab[2 * l];
-        extra_end = extra_first + tab[2 * l + 1];
+        extra_first = rect + uniform_int(tab[2 * l]);       // (vector loads of a uniform address: back to scalar registers)
+        extra_end = extra_first + uniform_int(tab[2 * l + 1]);
     }
     auto next_q = [&](int q) {
         if (a.deal_rows <= 0) return q + n_l;
@@ -349,22 +349,26 @@ UPX_HD void zoom_analysis_program(Ex& ex, const ZoomArgs& a, cf* lds_all, int wg
     // (zero extension of center_extraction.py:437-455); a unit past the end re-reads the current one (never used).
     auto request = [&](int tid, Thread& th, Unit u) {
         const int rho = tid % RG, sl = tid / RG;
-        const unsigned o = (unsigned)(D * sl + u.grp * RG + rho);
+        const unsigned o_lane = (unsigned)(D * sl + u.grp * RG + rho);
         const long long stride = (long long)D * SL;                       // samples between slots (uniform)
         const long long base = (long long)frame_of(u) * a.hop;            // first sample of the frame (uniform)
         const UPX_GLOBAL cf* in = opaque(a.in);
         const UPX_GLOBAL float* w_a = opaque(a.w_a);
         if (base + a.n <= a.t_in) {   // (uniform; both sides issue the same 32 loads)
+            const unsigned o = pin_lane(o_lane);   // (pinned inside the block that uses it)
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 th.pre[s] = gat_u(in, base + s * stride, o);
                 th.acc_c[s] = gat_u(w_a, s * stride, o);
             }
         } else {
+            const unsigned o = pin_lane(o_lane);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const bool inside = o < zoom_limit((long long)a.t_in - (base + s * stride));   // (uniform limit)
-                th.pre[s] = gat_u(in, inside ? base + s * stride : 0, inside ? o : 0u);
+                // (the uniform part stays uniform: clipped to the signal, which changes nothing for a lane that is inside)
+                const long long ub = base + s * stride < (long long)a.t_in ? base + s * stride : (long long)a.t_in - 1;
+                th.pre[s] = gat_u(in, ub, inside ? o : 0u);
                 const float w = gat_u(w_a, s * stride, o);
                 th.acc_c[s] = inside ? w : 0.f;
             }
@@ -543,8 +547,8 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     constexpr bool AHEAD_OLD = Z::SEEDS_LDS;
     const int D = a.d;
     const int sid = (role ? a.stream0_c : a.stream0) + stream_index;
-    const int m0 = zoom_stream_first(a, role, sid);
-    const int F = zoom_stream_frames(a, role, sid);
+    const int m0 = uniform_int(zoom_stream_first(a, role, sid));   // (table entries: vector loads of a uniform address)
+    const int F = uniform_int(zoom_stream_frames(a, role, sid));
     const int stride = D * SL;   // samples between slots
     // position in the launch's dispatch order (upx_zoom_synthesis_kernel): Ls/Rs workgroups, then the centre ones
     const int lin = role == 0 ? stream_index + a.ns_lr * grp : a.ns_lr * (D / RG) + stream_index + a.ns_c * grp;
@@ -574,7 +578,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
         Hop h;
         h.emit = j >= a.m_lo && j < a.m_hi && j < m0 + F;
         h.base = (long long)j * a.hop;
-        h.o = (unsigned)(D * sl + grp * RG + rho);
+        h.o = pin_lane((unsigned)(D * sl + grp * RG + rho));
         h.fast = h.emit && h.base + a.hop <= a.t_out;
         return h;
     };
@@ -596,7 +600,16 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     };
     auto emit = [&](UPX_GLOBAL float* plane, const Hop& h, int s, float v) {
         if (h.fast) {
+            // A plain store, not store_nt: with more residues than a workgroup holds (D > RG: bands 0-2 of C3, the default
+            // plan's 65 536 bands) a store instruction writes 64-byte segments, half a cache line each, and the streaming hint
+            // costs the write-only synthesis 4-7 % (A/B round 4: 0.181-0.190 vs 0.194-0.198 ms; contiguous 256-byte rows -
+            // D = RG, band 3 - do not care).  (Until round 4 the hint was silently lost here anyway: the optimiser merged the
+            // fast and the checked store paths and dropped the metadata.)
+#if defined(UPX_ZOOM_STORE_NT)
             store_nt(gat_u(plane, h.base + s * (long long)stride, h.o), v);
+#else
+            gat_u(plane, h.base + s * (long long)stride, h.o) = v;
+#endif
         } else if (h.emit) {
             if (h.o < zoom_limit((long long)a.t_out - (h.base + s * (long long)stride)))
                 gat_u(plane, h.base + s * (long long)stride, h.o) = v;
@@ -676,7 +689,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
     };
     auto fetch_old_in = [&](int tid, int t, cf* o8) {   // interior + accumulating: 2 HS unconditional loads
         const int tt = t < n_tr ? t : n_tr - 1;
-        const unsigned o = (unsigned)(D * (tid / RG) + grp * RG + tid % RG);
+        const unsigned o = pin_lane((unsigned)(D * (tid / RG) + grp * RG + tid % RG));
         UPX_GLOBAL float* p0 = role == 0 ? opaque(a.out_l) : opaque(a.out_c);
         UPX_GLOBAL float* p1 = role == 0 ? opaque(a.out_r) : opaque(a.out_c);
         const long long b0 = (long long)(role == 0 ? m0 + tt : m0 + 2 * tt) * a.hop;
@@ -725,7 +738,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
             if constexpr (EARLY_WINDOW) {
                 // the window of the last phase BEFORE the next long request (loads return in order: queued behind
                 // the spectrum prefetch the window would arrive with it); coalesced layout of that phase
-                const unsigned o = (unsigned)(D * (tid / RG) + grp * RG + tid % RG);
+                const unsigned o = pin_lane((unsigned)(D * (tid / RG) + grp * RG + tid % RG));
                 const UPX_GLOBAL float* w_s = opaque(a.w_s);
 #pragma unroll
                 for (int s = 0; s < 16; ++s) th.g0w[s] = gat_u(w_s, s * (long long)stride, o);
@@ -743,7 +756,7 @@ UPX_HD void zoom_synthesis_role(Ex& ex, const ZoomArgs& a, cf* lds_all, int stre
         // last pass in the coalesced layout; slot s = sample D (sl + SL s) + r of the frame
         ex.each([&, t, nonzero](int tid, Thread& th) {
             const int rho = tid % RG, sl = tid / RG;
-            const unsigned o = (unsigned)(D * sl + grp * RG + rho);
+            const unsigned o = pin_lane((unsigned)(D * sl + grp * RG + rho));
             // loads first, stores last: the old plane values of the hop(s) about to be emitted (band sum in list
             // order; HBM misses that the last pass and the overlap-add below cover in part) and the window
             cf old[HS];
