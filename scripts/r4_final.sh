@@ -24,4 +24,6 @@ for wl in c3 c4share default c1 c2; do
   timeout -k 10 600 bash scripts/pmc.sh r4_$wl --workload $wl > $O/pmc_$wl.log 2>&1 || echo "pmc $wl failed"
 done
 for seed in 401 402; do timeout -k 10 300 python scripts/gpu_fuzz.py $seed 150 > $O/fuzz_$seed.log 2>&1; tail -1 $O/fuzz_$seed.log; done
+timeout -k 10 120 python scripts/stream_chunk_rate.py > $O/stream_chunk_rate.txt 2>&1; cat $O/stream_chunk_rate.txt
+timeout -k 10 120 python scripts/wav_overlap_probe.py > $O/wav_overlap_probe.txt 2>&1; tail -2 $O/wav_overlap_probe.txt
 echo done

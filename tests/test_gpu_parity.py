@@ -1060,3 +1060,47 @@ def test_wav_pipeline_beyond_2_to_29_frames(ux):
         del out, got, ref, want
     finally:
         plan.close()
+
+
+def test_streamed_shard_api_misuse_and_piecewise_feed(ux):
+    """upx_wav_shard_open / _feed / _seal and _finish_async / _wait_piece: pieces of any length give the one-call result
+    (begin + finish) bit for bit when the chunk cut is the same, and misuse fails with ValueError instead of touching
+    memory: feeding without an open shard, too many frames, sealing early, waiting for a piece that does not exist."""
+    from upmix_amd import _lib
+    rng = np.random.default_rng(8)
+    n = 200_000
+    pcm = np.rint(np.clip(0.2 * rng.standard_normal((n, 2)), -0.99, 0.99) * 32767).astype("<i2")
+    raw = pcm.view(np.uint8).reshape(-1)
+    bands = ux.chain_bands([0, 300, 3000], 0.75, ux.make_blackman_harris, 48000, max_block_size=4096, threshold_factor=64,
+                           verbose=False)
+    plan = ux.DevicePlan(bands)
+    try:
+        ref, stats = plan.wav_pipeline(pcm, _lib.PCM16, 2, n, "split", _lib.PCM24)
+        with pytest.raises(ValueError):
+            plan.wav_shard_feed(raw[:400], 100)                              # nothing open
+        plan.wav_shard_open(_lib.PCM16, 2, n, n, n)
+        with pytest.raises(ValueError):
+            plan.wav_shard_seal()                                            # nothing fed yet
+        pos = 0
+        for piece in (1, 999, 65536, 7, 100_000, n):                         # ragged pieces, the last one clipped
+            k = min(piece, n - pos)
+            if k:
+                plan.wav_shard_feed(raw[pos * 4:(pos + k) * 4], k)
+                pos += k
+        with pytest.raises(ValueError):
+            plan.wav_shard_feed(raw[:4], 1)                                  # one frame too many
+        pin, pout = plan.wav_shard_seal()
+        assert pin == stats["peak_in"] and abs(pout - stats["overall_peak"]) <= 1e-7 * stats["overall_peak"]
+        payloads, n_pieces, per = plan.wav_shard_finish_async(stats["scale_factor"], "split", _lib.PCM24, n, piece_frames=30_000)
+        assert n_pieces == 7 and per == 30_000
+        with pytest.raises(ValueError):
+            plan.wav_shard_wait_piece(7)
+        for k in range(n_pieces):
+            plan.wav_shard_wait_piece(k)
+            for key in ref:                                                  # piece k is final as soon as it has landed
+                a, b = k * per * 6, min(n, (k + 1) * per) * 6
+                assert bytes(payloads[key][a:b]) == bytes(ref[key][a:b]), (key, k)
+        with pytest.raises(ValueError):
+            plan.wav_shard_finish_async(1.0, "split", _lib.PCM24, n)        # no shard open any more
+    finally:
+        plan.close()

@@ -1934,6 +1934,9 @@ int upx_wav_shard_finish_async(upx_plan* p, double scale, int mode, int out_form
     hipStream_t st = p->stream;
     p->wav_t0 = wall_ms();
     if (int rc = ensure_copy_streams(p)) return rc;
+    // (a caller that has not waited for every piece of the previous shard: its last download still reads the buffers the
+    // export kernels below write)
+    if (p->wav_pieces > 0) HIP_TRY(hipStreamWaitEvent(st, p->wav_down_ev[(size_t)p->wav_pieces - 1], 0));
     // export layout + quantisation piece by piece; a piece goes down (copy stream) while the next one is exported
     int64_t piece = piece_frames > 0 ? piece_frames : (p->knob_wav_chunk > 0 ? p->knob_wav_chunk : n);
     if (piece > n) piece = n;
