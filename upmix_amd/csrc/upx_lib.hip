@@ -63,6 +63,52 @@ __global__ void upx_zoom_seam_add_kernel(upx::ZoomArgs a, int n_lr, int n_c, int
         upx::zoom_seam_add(a, n_lr, n_c, tail, g);
 }
 
+// The same two passes with 16-byte accesses: one grid row per stream (blockIdx.y; no 64-bit division per element), four
+// consecutive samples per thread.  The host takes these when hop % 4 == 0 and the planes and the seam buffer are 16-byte
+// aligned (a tail row is then aligned as well: tail = (K-1) hop); results are those of the scalar passes, sample for sample.
+__device__ __forceinline__ void upx_add4(float* plane, long long n, const float* row, int i, long long t_out) {
+    if (n + 3 < t_out) {
+        float4 v = *reinterpret_cast<float4*>(plane + n);
+        const float4 s = *reinterpret_cast<const float4*>(row + i);
+        v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        *reinterpret_cast<float4*>(plane + n) = v;
+    } else {
+        for (int q = 0; q < 4 && n + q < t_out; ++q) plane[n + q] += row[i + q];
+    }
+}
+__global__ void upx_stream_seam_add4_kernel(upx::BandArgs a, int n_streams, int tail, int hop) {
+    const int sid = blockIdx.y;
+    if (sid >= n_streams - 1) return;                       // the last stream's tail lies beyond the emitted range
+    const long long m = upx::stream_first(a, sid + 1);
+    if (m >= a.m_hi) return;
+    const float* row = a.seam + (size_t)sid * 3 * tail;
+    for (int i = 4 * (blockIdx.x * blockDim.x + threadIdx.x); i < tail; i += 4 * gridDim.x * blockDim.x) {
+        const long long n = m * hop + i;
+        if (n < 0 || n >= a.t_out || m + i / hop >= a.m_hi) continue;   // (hop % 4 == 0: the four samples share a block)
+        upx_add4(a.out_c, n, row, i, a.t_out);
+        upx_add4(a.out_l, n, row + tail, i, a.t_out);
+        upx_add4(a.out_r, n, row + 2 * (size_t)tail, i, a.t_out);
+    }
+}
+__global__ void upx_zoom_seam_add4_kernel(upx::ZoomArgs a, int n_lr, int n_c, int tail) {
+    const int role = (int)blockIdx.y >= n_lr ? 1 : 0;
+    const int sid = role ? (int)blockIdx.y - n_lr : (int)blockIdx.y;
+    if (sid >= (role ? n_c : n_lr) - 1) return;
+    const long long m = upx::zoom_stream_first(a, role, sid + 1);
+    if (m >= a.m_hi) return;
+    for (int i = 4 * (blockIdx.x * blockDim.x + threadIdx.x); i < tail; i += 4 * gridDim.x * blockDim.x) {
+        const long long n = m * a.hop + i;
+        if (n < 0 || n >= a.t_out || m + i / a.hop >= a.m_hi) continue;
+        if (role) {
+            upx_add4(a.out_c, n, a.seam_c + (size_t)sid * tail, i, a.t_out);
+        } else {
+            const float* row = a.seam + (size_t)sid * 2 * tail;
+            upx_add4(a.out_l, n, row, i, a.t_out);
+            upx_add4(a.out_r, n, row + tail, i, a.t_out);
+        }
+    }
+}
+
 // max |x| as a bit pattern: non-negative floats order like their bit patterns, and a NaN (sign cleared) lies above
 // every number, so a NaN anywhere gives NaN - what np.max(np.abs(.)) gives main.py:53, :85-88.
 // One atomic per WORKGROUP (round 3 issued one per wave: 8192 atomics on one address serialise in the L2 - 100 us for a
@@ -315,6 +361,7 @@ struct upx_plan {
     int knob_zoom_a_age = 8;                // UPX_ZOOM_A_AGE: % by which each later dispatch round of the band-limited analysis runs slower (0 = equal shares)
     int knob_zoom_edge_percent = 76;        // UPX_ZOOM_EDGE_PERCENT: length of the first / last synthesis stream of a signal (100 = like the others)
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
+    int knob_seam_vec = 1;                  // UPX_SEAM_VEC: stream-seam passes with 16-byte accesses where alignment allows (0: scalar passes)
     int knob_first_band = -1;               // UPX_FIRST_BAND: launch this band's group first (-1: list order, the reference's sum order)
     int knob_min_stream_frames = 4;         // UPX_MIN_STREAM_FRAMES: shortest stream of a fused launch that does not fill the chip (>= K, even)
     int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
@@ -457,6 +504,11 @@ int grid_reduce(long long n) {
     long long g = (n / 4 + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
 }
+// the 16-byte seam passes apply: hop a multiple of four samples, planes and seam buffer 16-byte aligned (UPX_SEAM_VEC=0: never)
+bool seam_vec_ok(const upx_plan* p, const float* c, const float* l, const float* r, int hop) {
+    const size_t bits = (size_t)c | (size_t)l | (size_t)r | (size_t)p->d_seam;
+    return p->knob_seam_vec != 0 && hop % 4 == 0 && (bits & 15u) == 0;
+}
 int grid_for(long long n) {
     long long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -523,6 +575,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_MIN_STREAM_FRAMES")) p->knob_min_stream_frames = std::atoi(e);
     if (const char* e = std::getenv("UPX_WAV_CHUNK")) p->knob_wav_chunk = std::atoll(e);
     if (const char* e = std::getenv("UPX_FIRST_BAND")) p->knob_first_band = std::atoi(e);
+    if (const char* e = std::getenv("UPX_SEAM_VEC")) p->knob_seam_vec = std::atoi(e);
     if (const char* e = std::getenv("UPX_WAV_UNIFORM")) p->knob_wav_uniform = std::atoi(e);
     if (const char* e = std::getenv("UPX_WAV_KERNEL_RATE")) p->knob_wav_kernel_rate = std::atof(e);
     if (const char* e = std::getenv("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
@@ -1144,9 +1197,14 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                 ++n_launches;
             }
             if (p->timing) s.ring_mid_n[slot] = n_mid;
-            if (n_lr_total > 1 || n_c_total > 1)
-                hipLaunchKernelGGL(upx_zoom_seam_add_kernel, dim3(grid_for((n_lr_total + n_c_total) * tail)), dim3(256), 0,
-                                   p->stream, a, (int)n_lr_total, (int)n_c_total, (int)tail);
+            if (n_lr_total > 1 || n_c_total > 1) {
+                if (seam_vec_ok(p, d_c, d_l, d_r, s.hop) && n_lr_total + n_c_total <= 65535)
+                    hipLaunchKernelGGL(upx_zoom_seam_add4_kernel, dim3((unsigned)((tail / 4 + 255) / 256), (unsigned)(n_lr_total + n_c_total)),
+                                       dim3(256), 0, p->stream, a, (int)n_lr_total, (int)n_c_total, (int)tail);
+                else
+                    hipLaunchKernelGGL(upx_zoom_seam_add_kernel, dim3(grid_for((n_lr_total + n_c_total) * tail)), dim3(256), 0,
+                                       p->stream, a, (int)n_lr_total, (int)n_c_total, (int)tail);
+            }
             if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
             s.last_wg = (int)((n_lr_total + n_c_total) * groups);
             s.last_f = tab_lr[1] - tab_lr[0];
@@ -1253,9 +1311,14 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         s.fill_wg_a = s.fill_slots_a = 0;
         if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
         s.kern->launch(a, (int)n_wg, p->stream);
-        if (n_streams > 1)
-            hipLaunchKernelGGL(upx_stream_seam_add_kernel, dim3(grid_for(n_streams * tail)), dim3(256), 0, p->stream, a,
-                               (int)n_streams, (int)tail, s.hop);
+        if (n_streams > 1) {
+            if (seam_vec_ok(p, d_c, d_l, d_r, s.hop) && n_streams <= 65535)
+                hipLaunchKernelGGL(upx_stream_seam_add4_kernel, dim3((unsigned)((tail / 4 + 255) / 256), (unsigned)n_streams), dim3(256), 0,
+                                   p->stream, a, (int)n_streams, (int)tail, s.hop);
+            else
+                hipLaunchKernelGGL(upx_stream_seam_add_kernel, dim3(grid_for(n_streams * tail)), dim3(256), 0, p->stream, a,
+                                   (int)n_streams, (int)tail, s.hop);
+        }
         if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
     }
     HIP_TRY(hipGetLastError());
