@@ -1104,3 +1104,49 @@ def test_streamed_shard_api_misuse_and_piecewise_feed(ux):
             plan.wav_shard_finish_async(1.0, "split", _lib.PCM24, n)        # no shard open any more
     finally:
         plan.close()
+
+
+def test_wav_pipeline_full_c4_share_chunked_equals_whole(ux, orc, monkeypatch):
+    """BASELINE configs[3], one GPU's share (86.4 M frames at 96 kHz, plan [8192 x4, 2048, 512]) through the device codec:
+    the default chunk schedule (the shard in ~10 chunks, their kernels under the uploads) against the same call as ONE chunk -
+    identical peaks and scale, payloads equal except <= 1 LSB behind chunk seams - and the payload against the in-memory
+    entry + host export on a window (the codec around the kernels: PCM16 in, stereo_sum PCM16 out)."""
+    from upmix_amd import _lib, export
+    total, sr = 86_400_000, 96000
+    rng = np.random.default_rng(13)
+    pcm = np.empty((total, 2), dtype="<i2")
+    for a in range(0, total, 1 << 23):                       # (in pieces: no 1.4 GB float64 temporary)
+        b = min(total, a + (1 << 23))
+        pcm[a:b] = np.rint(np.clip(0.2 * rng.standard_normal((b - a, 2), dtype=np.float32), -0.99, 0.99) * 32767).astype("<i2")
+    bands = gpu_chain(ux, [0, 30, 120, 480, 1920, 7680], sr, 8192, 32)
+    assert [b.block_size for b in bands] == [8192, 8192, 8192, 8192, 2048, 512]
+    monkeypatch.setenv("UPX_WAV_CHUNK", "0")
+    whole = ux.DevicePlan(bands)
+    monkeypatch.delenv("UPX_WAV_CHUNK")
+    cut = ux.DevicePlan(bands)
+    try:
+        ref, ref_stats = whole.wav_pipeline(pcm, _lib.PCM16, 2, total, "stereo_sum", _lib.PCM16)
+        got, stats = cut.wav_pipeline(pcm, _lib.PCM16, 2, total, "stereo_sum", _lib.PCM16)
+        assert stats["peak_in"] == ref_stats["peak_in"]
+        assert abs(stats["overall_peak"] - ref_stats["overall_peak"]) <= 1e-6 * ref_stats["overall_peak"]
+        a = got["Sum"].view("<i2").astype(np.int32)
+        b = ref["Sum"].view("<i2").astype(np.int32)
+        assert a.shape == b.shape == (2 * total,)
+        # (every launch of every chunk cuts its streams anew: ~1e-7 association differences behind tens of thousands of stream
+        # seams, a few of which cross a 16-bit rounding boundary: 7 048 of 172.8 M samples when this was written)
+        assert np.max(np.abs(a - b)) <= 1 and np.count_nonzero(a != b) <= a.size // 10000
+        # a window of the payload against the in-memory kernels + the host's export arithmetic (main.py:85-97, :140-157)
+        lo, n = 40_000_000 // 4096 * 4096, 400_000
+        seg = pcm[lo - 65536:lo + n + 65536].astype(np.float32) / 32768.0
+        c, l, r = cut.process(seg)
+        scale = np.float64(stats["scale_factor"])
+        for p in (c, l, r):
+            p *= scale
+        want = export.export_arrays("stereo_sum", c, l, r)["Sum"][65536:65536 + n]
+        q = np.clip(np.rint(want.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int32)
+        seg_got = got["Sum"].view("<i2").reshape(-1, 2)[lo:lo + n].astype(np.int32)
+        assert np.max(np.abs(seg_got - q)) <= 1                                     # (the restarted window fades in: 65536 skipped)
+        del ref, got, a, b
+    finally:
+        whole.close()
+        cut.close()
