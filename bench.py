@@ -593,6 +593,10 @@ def main():
                 "bands_in_launch": dom["bands"],
                 "avg_launch_ms": dom["ms"],
                 "traffic_ratio": dom["traffic_ratio"],
+                # what a streaming kernel with these kernels' lane pattern reaches on this part (scripts/microbench/atomic_rmw.hip,
+                # store 5.3 TB/s, load + add + store 5.5 TB/s): `peak` stays the guide's 8 TB/s
+                "measured_streaming_GBps": 5500.0,
+                "traffic_frac_of_measured_streaming": None if not traffic else round(traffic / (dom["ms"] * 1e-3) / 1e9 / 5500.0, 4),
                 "limiter": "not HBM bandwidth: VALU issue + LDS exchanges at 2-4 waves per SIMD, and for the fused kernels the "
                            "in-order vector L1 (DESIGN.md 5, 8); `valu.executed` is the ceiling that binds",
             },
