@@ -95,6 +95,22 @@ int upx_process_chunked(upx_plan* plan, const float* stereo, int64_t n_samples, 
                         float* out_r, int64_t chunk);
 
 /*
+ * The same call on the arrays the reference's caller holds (main.py:49-50, 78-80 hand
+ * extract_center_left_right_multi_band_in_memory two float64 COLUMN VIEWS of one [T][2] array; center_extraction.py:477-482
+ * takes any real arrays): `left` / `right` point at sample 0 of either channel, `stride` is the distance between
+ * consecutive samples of a channel in elements:
+ *     stride 2 and right == left + one element   the two columns of one C-contiguous interleaved [T][2] array
+ *     stride 1                                   two contiguous arrays
+ * (anything else: UPX_ERR_UNSUPPORTED - gather on the host).  sample_format: UPX_SAMPLE_F32 | UPX_SAMPLE_F64.  The samples
+ * go over the link as they are, chunk by chunk like upx_process, and are cast to float32 and interleaved ON THE DEVICE:
+ * the same round-to-nearest cast the host would make, so the result is bit-identical to upx_process on
+ * float32(interleave(left, right)) - without two strided host passes over the signal before the first byte moves.
+ */
+enum { UPX_SAMPLE_F32 = 0, UPX_SAMPLE_F64 = 1 };
+int upx_process_lr(upx_plan* plan, const void* left, const void* right, int sample_format, int64_t stride,
+                   int64_t n_samples, float* out_c, float* out_l, float* out_r);
+
+/*
  * A batch of independent tracks through ONE plan (BASELINE configs[4]; the reference's analogue is running
  * main.py:36-80 once per file): track t is stereo[t] ([n_samples[t]][2] float32) -> out_c[t] / out_l[t] / out_r[t]
  * (float32 [n_samples[t]]).  The tracks (cut into chunks exactly as upx_process cuts a long signal) form one queue
@@ -130,6 +146,16 @@ int upx_sync(upx_plan* plan);
  */
 int upx_process_device(upx_plan* plan, const float* d_stereo, int64_t t_in, int64_t own_len, float* d_c,
                        float* d_l, float* d_r, int64_t t_out);
+
+/*
+ * Prepares the plan for upx_process_device calls of this shape: launch geometry, stream tables (uploaded), seam and
+ * scratch buffers - everything the FIRST call of a shape otherwise allocates, uploads and synchronises for on the way
+ * (a few tenths of a millisecond: the software part of a cold call; the rest of a cold call is the card's clock ramp).
+ * Launches nothing and touches no signal buffer.  A later upx_process_device(plan, ., t_in, own_len, ., ., ., t_out) then
+ * only enqueues kernels.  Blocking.  The reference has no counterpart (its state is built in
+ * MultiBandExtractorAccu.__init__, center_extraction.py:240-271, which upx_plan_create mirrors).
+ */
+int upx_plan_reserve(upx_plan* plan, int64_t t_in, int64_t own_len, int64_t t_out);
 
 /* Per-band kernel timing with HIP events on the plan's stream.  enable: 0 off, 1 on (forgets the calls recorded so far),
  * 2 resume / 3 pause without forgetting: the events cost ~2 us each (24 us of a 1.45 ms call with ten of them), so a

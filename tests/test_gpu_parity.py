@@ -381,7 +381,13 @@ def test_results_live_in_pooled_page_locked_memory(ux, orc, monkeypatch):
     plan = ux.DevicePlan(bands)
     x = orc.synthetic_stereo(300000, 21)
     y = orc.synthetic_stereo(300000, 22)
+    # the FIRST call that asks for a size gets plain NumPy arrays: a one-shot process (the reference's flow, main.py:78-80)
+    # must not pay for pinning blocks it never reuses; the second call has proven reuse and pins (hostmem.PinnedPool.take)
+    first = plan.process(x)
+    assert all(o.base is None for o in first) and hostmem.POOL._held == 0
     a = plan.process(x)
+    assert all(o.base is not None for o in a) and all(np.array_equal(o, q) for o, q in zip(a, first))
+    del first
     keep = [o.copy() for o in a]
     b = plan.process(y)                                # `a` is still held: `b` must not land on its blocks
     assert all(np.array_equal(o, k) for o, k in zip(a, keep))
@@ -403,6 +409,82 @@ def test_results_live_in_pooled_page_locked_memory(ux, orc, monkeypatch):
     left *= 2.0                                        # results are the caller's to scale in place (main.py:95-97)
     assert np.array_equal(c[1], keep[1] * np.float32(2.0))
     plan.close()
+
+
+def test_drop_in_entry_takes_the_callers_arrays_as_they_are(ux, orc):
+    """
+    main.py:49-50, 78-80 hands extract_center_left_right_multi_band_in_memory two float64 COLUMN VIEWS of one [T, 2]
+    array.  They go to the library as they are (upx_process_lr: cast to float32 and interleaved on the device); the
+    result is bit-identical to the host cast + interleave + upx_process, for float64 / float32, column views / separate
+    contiguous arrays, short signals and signals that stream in chunks; other dtypes and strides take the host cast.
+    Values beyond the float32 range become infinite exactly as np.asarray(x, float32) makes them.
+    """
+    bands = gpu_chain(ux, [0, 300, 3000], 48000, 4096, 64)
+    plan = ux.DevicePlan(bands)
+    for total in (1, 777, 300001, (1 << 23) + 4097 + 1):          # the last one streams (two chunks of 2^22 and a ragged rest)
+        wave = orc.synthetic_stereo(total, 5).astype(np.float64)
+        wave[total // 2:, 1] *= 1.0 + 2.0 ** -30                  # values that are not float32 numbers: the cast rounds
+        ref = plan.process(wave.astype(np.float32))
+        cases = {
+            "f64 column views": (wave[:, 0], wave[:, 1]),
+            "f64 contiguous": (wave[:, 0].copy(), wave[:, 1].copy()),
+            "f32 column views": (wave.astype(np.float32)[:, 0], wave.astype(np.float32)[:, 1]),
+            "f32 contiguous": (wave[:, 0].astype(np.float32), wave[:, 1].astype(np.float32)),
+            "columns of a [T, 3] array (other strides: host cast)": (np.pad(wave, ((0, 0), (0, 1)))[:, 0], np.pad(wave, ((0, 0), (0, 1)))[:, 1]),
+            "int16 (host cast)": ((wave[:, 0] * 1000).astype(np.int16), (wave[:, 1] * 1000).astype(np.int16)),
+        }
+        for name, (L, R) in cases.items():
+            got = plan.process_lr(L, R)
+            if name.startswith("int16"):
+                want = plan.process(np.stack([L.astype(np.float32), R.astype(np.float32)], axis=1))
+            else:
+                want = ref
+            for g, w in zip(got, want):
+                assert g.dtype == np.float32 and g.shape == (total,) and np.array_equal(g, w), (name, total)
+    # the module-level entry and the per-band entry go the same way
+    wave = orc.synthetic_stereo(50000, 6).astype(np.float64)
+    ref = plan.process(wave.astype(np.float32))
+    for g, w in zip(ux.extract_center_left_right_multi_band_in_memory(wave[:, 0], wave[:, 1], 48000, bands), ref):
+        assert np.array_equal(g, w)
+    one = bands[2].process_all_blocks(wave[:, 0], wave[:, 1])
+    one_ref = ux.DevicePlan([bands[2]])
+    for g, w in zip(one, one_ref.process(wave.astype(np.float32))):
+        assert np.array_equal(g, w)
+    one_ref.close()
+    # beyond the float32 range: infinity on the device as on the host (documented: non-finite output on those frames)
+    big = wave.copy()
+    big[100, 0] = 1e300
+    got = plan.process_lr(big[:, 0], big[:, 1])
+    with np.errstate(over="ignore"):
+        want = plan.process(big.astype(np.float32))
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w, equal_nan=True)
+    with pytest.raises(ValueError):
+        plan.process_lr(wave[:, 0], wave[:-1, 1])
+    assert all(o.shape == (0,) for o in plan.process_lr(np.zeros(0), np.zeros(0)))
+    plan.close()
+
+
+def test_dual_stream_experiment_kernels_agree(ux, orc, monkeypatch):
+    """UPX_DUAL=1 (round-5 experiment, upx_reg_fused_dual.hip): two stream sets per wave at one wave per SIMD run the same
+    phases on the same data - bit-identical planes to the default kernels except the float32 association on the blocks
+    behind stream seams (the stream cut differs)."""
+    x = orc.synthetic_stereo(1200000, 8)
+    edges = [0, 30, 120, 480, 1920, 7680]
+    outs, names = {}, {}
+    for dual in ("0", "1"):
+        monkeypatch.setenv("UPX_DUAL", dual)
+        bands = gpu_chain(ux, edges, 48000, 8192, 32)
+        plan = ux.DevicePlan(bands)
+        names[dual] = [plan.band_kernel_name(i) for i in range(len(bands))]
+        outs[dual] = plan.process(x)
+        plan.close()
+    assert sum("dual" in n for n in names["1"]) == 2 and not any("dual" in n for n in names["0"])
+    ref_bands = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, 48000, max_block_size=8192, threshold_factor=32)
+    ref = orc.extract_multi_band(x[:60000, 0].astype(np.float64), x[:60000, 1].astype(np.float64), ref_bands)
+    for a, b, r in zip(outs["0"], outs["1"], ref):
+        assert rms(a.astype(np.float64) - b) < 1e-7
+        close(b[:50000], r[:50000])
 
 
 def test_rccl_single_rank_communicator(ux, orc):

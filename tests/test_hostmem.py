@@ -102,8 +102,11 @@ def test_empty_gives_shaped_typed_arrays(monkeypatch):
 
 
 def test_a_result_that_outlives_every_plan_is_unpinned_when_it_dies(monkeypatch):
-    """Round-3 advisor finding: blocks still leased when the last plan closed stayed page-locked for good.  After trim()
-    (= the process' last plan closed) a dying array frees its block at once; a new take() (= a new plan) resumes pooling."""
+    """Round-3 advisor finding: blocks still leased when the last plan closed stayed page-locked for good.  Round-4 finding:
+    the finaliser that fixed it called hipHostFree (a device-synchronising call) and updated the accounting without the
+    lock, at whatever allocation point the garbage collector ran.  Now the finaliser only appends; after trim() (= the
+    process' last plan closed) a sweeper thread unpins returned blocks under the lock; a new take() (= a new plan) resumes pooling."""
+    import time
     pool, fake = make_pool(monkeypatch, 64 << 20)
     kept = pool.take(1000, None)
     idle = pool.take(1000, None)
@@ -111,14 +114,55 @@ def test_a_result_that_outlives_every_plan_is_unpinned_when_it_dies(monkeypatch)
     gc.collect()
     pool.trim(None)                                   # last plan closes: the idle block goes, `kept` is still leased
     assert fake.frees == 1 and pool._held == hostmem._GRANULE and not pool.plans_live
+    frees_in_finaliser = []
+    real_free = fake.upx_host_free
+    import threading
+    main = threading.current_thread()
+
+    def free_spy(plan, p):
+        frees_in_finaliser.append(threading.current_thread() is main)
+        return real_free(plan, p)
+    fake.upx_host_free = free_spy
     del kept
     gc.collect()
+    assert fake.frees == 1 and len(pool._returned) + len(pool._free.get(hostmem._GRANULE, [])) == 1   # nothing freed in the finaliser
+    for _ in range(40):                               # the sweeper (0.25 s period) unpins it
+        if fake.frees == 2:
+            break
+        time.sleep(0.1)
     assert fake.frees == 2 and pool._held == 0 and not fake.bufs and not pool._returned
+    assert frees_in_finaliser == [False]              # ... on its own thread, never on the thread the finaliser ran on
+    for _ in range(20):
+        if pool._sweeper is None:
+            break
+        time.sleep(0.1)
+    assert pool._sweeper is None                      # nothing leased any more: the thread has ended
     again = pool.take(10, None)                       # a new plan: pooling as before
     assert pool.plans_live and fake.allocs == 3
     del again
     gc.collect()
     assert fake.frees == 2 and len(pool._returned) == 1
+
+
+def test_lazy_pinning_first_call_gets_pageable_arrays(monkeypatch):
+    """The reference's flow is one call per process (main.py:78-80): the first call that asks for a capacity must not pay
+    for pinning it (92 ms against a 41 ms call for 10 min of audio); the second call has proven reuse and pins."""
+    pool, fake = make_pool(monkeypatch, 64 << 20)
+    t1 = pool.new_call()
+    first = [pool.take(1000, None, lazy=t1) for _ in range(3)]           # one call, three planes of one capacity
+    assert fake.allocs == 0 and all(a.base is None and a.shape == (1000,) for a in first)
+    t2 = pool.new_call()
+    second = [pool.take(1000, None, lazy=t2) for _ in range(3)]
+    assert fake.allocs == 3 and all(a.base is not None for a in second)
+    other = pool.take(5 * hostmem._GRANULE, None, lazy=t2)               # another capacity: its own first call
+    assert other.base is None and fake.allocs == 3
+    del second
+    gc.collect()
+    t3 = pool.new_call()
+    third = [pool.take(900, None, lazy=t3) for _ in range(3)]            # idle blocks are used whoever asks
+    assert fake.allocs == 3 and all(a.base is not None for a in third)
+    now = pool.take(3 * hostmem._GRANULE, None)                          # not lazy (staging buffers of the file entries): pinned at once
+    assert now.base is not None and fake.allocs == 4
 
 
 def test_default_limit_scales_with_ram_and_ranks(tmp_path):

@@ -24,6 +24,7 @@ UPX_ERR_NOMEM = -6
 UNIQUE_ID_BYTES = 128
 PCM16, PCM24, PCM32, F32 = 16, 24, 32, 1032
 EXPORT_STEREO_SUM, EXPORT_SPLIT, EXPORT_AB = 0, 1, 2
+SAMPLE_F32, SAMPLE_F64 = 0, 1
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -40,6 +41,7 @@ SIGNATURES = {
     "upx_plan_set_blocks_per_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "upx_process": (C.c_int, [C.c_void_p, f32p, C.c_int64, f32p, f32p, f32p]),
     "upx_process_chunked": (C.c_int, [C.c_void_p, f32p, C.c_int64, f32p, f32p, f32p, C.c_int64]),
+    "upx_process_lr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, f32p, f32p, f32p]),
     "upx_process_tracks": (C.c_int, [C.c_void_p, C.c_int32, vpp, C.POINTER(C.c_int64), vpp, vpp, vpp]),
     "upx_dev_alloc": (C.c_int, [C.c_void_p, vpp, C.c_size_t]),
     "upx_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -51,6 +53,7 @@ SIGNATURES = {
     "upx_sync": (C.c_int, [C.c_void_p]),
     "upx_process_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int64]),
+    "upx_plan_reserve": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "upx_plan_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "upx_plan_band_times_ms": (C.c_int, [C.c_void_p, f32p, C.c_int]),
     "upx_plan_band_times_sum_ms": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_int]),

@@ -198,7 +198,10 @@ UPX_HD cf lds_load(const cf* p) { return *p; }
 #endif
 // Stops the instruction scheduler from interleaving independent unrolled
 // iterations across this point (it otherwise trades ~130 extra VGPRs for ILP).
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(UPX_NO_SCHED_FENCE)
+#define UPX_SCHED_FENCE() ((void)0)
+#define UPX_ALL(c) (__builtin_amdgcn_ballot_w64(!(c)) == 0ull)
+#elif defined(__HIP_DEVICE_COMPILE__)
 #define UPX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define UPX_ALL(c) (__builtin_amdgcn_ballot_w64(!(c)) == 0ull)   // true on every active lane of the wave
 #else

@@ -282,6 +282,7 @@ struct Entry {
 //   variant 1:  8 points per lane, register budget for 4 waves/SIMD (128 VGPRs)
 //   variant 2: 16 points per lane, plain Stockham schedule for every size
 const KernelEntry* find_kernel_default(int log2n, int k, int variant);   // variants 0, 10, 100+
+const KernelEntry* find_kernel_dual(int log2n, int live_s1);             // experiment: two stream sets per wave (upx_reg_fused_dual.hip)
 const KernelEntry* find_kernel_p8(int log2n, int k);                     // variant 1
 const KernelEntry* find_kernel_plain(int log2n, int k);                  // variant 2
 // (log2 P, residues per workgroup, K) -> kernels of the band-limited path

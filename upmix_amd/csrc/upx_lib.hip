@@ -5,6 +5,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -154,6 +155,25 @@ __device__ __forceinline__ void upx_absmax_body(const float* x, long long n, uns
 __global__ void upx_scale_kernel(float* x, long long n, float s) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         x[i] *= s;
+}
+
+// upx_process_lr: a work item's samples as the caller holds them -> the interleaved float32 [n][2] the kernels read.
+// raw = interleaved [n][2] (planar == 0) or left[n] | right[n] (planar == 1) of float32 / float64 (f64 != 0).  The cast is
+// the one the host entry used to make (np.asarray(x, float32): round to nearest even, infinity beyond the float32 range).
+__global__ void upx_samples_to_stereo_kernel(const void* raw, int f64, int planar, long long n, float2* stereo) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float l, r;
+        if (f64) {
+            const double* d = static_cast<const double*>(raw);
+            if (planar) { l = (float)d[i]; r = (float)d[n + i]; }
+            else { const double2 v = reinterpret_cast<const double2*>(d)[i]; l = (float)v.x; r = (float)v.y; }
+        } else {
+            const float* f = static_cast<const float*>(raw);
+            if (planar) { l = f[i]; r = f[n + i]; }
+            else { const float2 v = reinterpret_cast<const float2*>(f)[i]; l = v.x; r = v.y; }
+        }
+        stereo[i] = make_float2(l, r);
+    }
 }
 
 // ---- device-side WAV codec + export layouts (main.py:43-55, 85-97, 110-157) -------------------
@@ -347,6 +367,7 @@ struct upx_plan {
     std::vector<BandState> bands;
     std::map<int, upx::cf*> tw;   // log2n -> device twiddles
     bool timing = false;
+    bool dry_run = false;           // upx_plan_reserve: upx_process_device prepares (geometry, tables, buffers) and launches nothing
     bool timed_once = false;
     long long timed_calls = 0;      // timed upx_process_device calls since timing was enabled
     unsigned int* d_scalar = nullptr;
@@ -363,6 +384,7 @@ struct upx_plan {
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
     int knob_seam_vec = 1;                  // UPX_SEAM_VEC: stream-seam passes with 16-byte accesses where alignment allows (0: scalar passes)
     int knob_first_band = -1;               // UPX_FIRST_BAND: launch this band's group first (-1: list order, the reference's sum order)
+    int knob_band_rotate = 0;               // UPX_BAND_ROTATE (experiment): the launch groups start this many groups into the list (another sum association)
     int knob_min_stream_frames = 4;         // UPX_MIN_STREAM_FRAMES: shortest stream of a fused launch that does not fill the chip (>= K, even)
     int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
     float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
@@ -377,6 +399,8 @@ struct upx_plan {
     float* d_pipe_in[2] = {nullptr, nullptr};
     float* d_pipe_out[2] = {nullptr, nullptr};
     size_t pipe_in_floats = 0, pipe_out_floats = 0;
+    void* d_pipe_raw[2] = {nullptr, nullptr};   // upx_process_lr: a work item's samples as the caller holds them
+    size_t pipe_raw_bytes = 0;
     // device buffers of upx_wav_pipeline, kept between calls (grow only): pcm in, stereo, planes, 3 outputs
     void* d_wav[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t wav_cap[6] = {0, 0, 0, 0, 0, 0};
@@ -585,6 +609,11 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         p->n_cu = prop.multiProcessorCount;
+    // UPX_N_CU (experiment): the launch geometry is cut for this many compute units, e.g. half the chip for each of two
+    // plans whose launches are meant to be resident side by side (scripts/r5_two_tiles.py)
+    if (const char* e = std::getenv("UPX_N_CU"))
+        if (std::atoi(e) >= 8) p->n_cu = std::atoi(e);
+    if (const char* e = std::getenv("UPX_BAND_ROTATE")) p->knob_band_rotate = std::atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&p->d_scalar, sizeof(unsigned int)));
     p->bands.resize(n_bands);
@@ -783,6 +812,15 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                         for (int a0 = lo > 1 ? 1 : lo; a0 >= 0 && !live; --a0)
                             if (a0 > 0 || b1 < 8) live = find_kernel(s.log2n, 4, 100 + 10 * a0 + b1);
                     if (live && live->layout == s.kern->layout) one = live;
+                    // UPX_DUAL = 1 (experiment): two stream sets per wave, one wave per SIMD (upx_reg_fused_dual.hip);
+                    // = 2: the N = 256 launch only, = 3: the N = 1024 launch only
+                    if (const char* e = std::getenv("UPX_DUAL")) {
+                        const int mode = std::atoi(e);
+                        const bool want = mode == 1 || (mode == 2 && s.log2n == 8) || (mode == 3 && s.log2n == 10);
+                        const KernelEntry* dual = want ? find_kernel_dual(s.log2n, live == one ? hi : 0) : nullptr;
+                        if (want && !dual) dual = find_kernel_dual(s.log2n, 0);
+                        if (dual && dual->layout == s.kern->layout) one = dual;
+                    }
                 }
                 if (int e = one->prepare())
                     return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
@@ -831,6 +869,7 @@ void upx_plan_destroy(upx_plan* p) {
     for (int i = 0; i < 2; ++i) {
         if (p->d_pipe_in[i]) (void)hipFree(p->d_pipe_in[i]);
         if (p->d_pipe_out[i]) (void)hipFree(p->d_pipe_out[i]);
+        if (p->d_pipe_raw[i]) (void)hipFree(p->d_pipe_raw[i]);
         if (p->ev_h2d[i]) (void)hipEventDestroy(p->ev_h2d[i]);
         if (p->ev_comp[i]) (void)hipEventDestroy(p->ev_comp[i]);
     }
@@ -912,8 +951,12 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
     if (t_out == 0) return UPX_OK;
     if (t_in >= (1LL << 29) || t_out >= (1LL << 29))
         return fail(UPX_ERR_INVALID, "upx_process_device: at most 2^29-1 samples per call (shard longer signals)");
-    if (!d_stereo || !d_c || !d_l || !d_r) return fail(UPX_ERR_INVALID, "upx_process_device: NULL buffer");
+    // upx_plan_reserve: everything this call would do on the host - launch geometry, stream tables, seam / scratch sizes and
+    // their allocations and uploads - without the launches (no buffer is touched, the pointers may be NULL)
+    const bool dry = p->dry_run;
+    if (!dry && (!d_stereo || !d_c || !d_l || !d_r)) return fail(UPX_ERR_INVALID, "upx_process_device: NULL buffer");
     HIP_TRY(hipSetDevice(p->device));
+    if (dry && (t_in == 0 || own_len == 0)) return UPX_OK;
     if (t_in == 0 || own_len == 0) {   // nothing to transform: the result is silence
         HIP_TRY(hipMemsetAsync(d_c, 0, (size_t)t_out * sizeof(float), p->stream));
         HIP_TRY(hipMemsetAsync(d_l, 0, (size_t)t_out * sizeof(float), p->stream));
@@ -921,10 +964,12 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         for (auto& s : p->bands) s.last_wg = 0;
         return UPX_OK;
     }
+    const bool timing = p->timing && !dry;
     const int slot = (int)(p->timed_calls % kTimingSlots);
     for (size_t b = 0; b < p->bands.size(); ++b) {
         BandState& s = p->bands[b];
         s.last_wg = 0;
+        if (dry) continue;
         s.ev0 = s.ring0[slot];
         s.ev1 = s.ring1[slot];
         s.ring_used[slot] = 0;
@@ -940,6 +985,13 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         if (lead != 0) order.push_back(lead);
         for (size_t b = 0; b < p->bands.size(); ++b)
             if (b != lead || lead == 0) order.push_back(b);
+    }
+    if (p->knob_band_rotate > 0) {
+        std::vector<size_t> leaders;
+        for (size_t b : order)
+            if (p->bands[b].group_size > 0) leaders.push_back(b);
+        std::rotate(leaders.begin(), leaders.begin() + (p->knob_band_rotate % (int)leaders.size()), leaders.end());
+        order = leaders;
     }
     const size_t first_launch = order.front();
     for (size_t b : order) {
@@ -971,15 +1023,15 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             a.hop = s.hop; a.kf = s.k;
             a.j_lo = 0; a.j_hi = (int)j_hi; a.ch = ch;
             a.accumulate = b == first_launch ? 0 : 1;
-            if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+            if (timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
             int n_chunks = 0;
             for (long long m0 = 0; m0 < m_hi; m0 += emit, ++n_chunks) {
                 a.j0 = (int)m0 - halo;
                 a.m0 = (int)m0;
                 a.m1 = (int)(m0 + emit < m_hi ? m0 + emit : m_hi);
-                s.big->chunk(a, p->stream);
+                if (!dry) s.big->chunk(a, p->stream);
             }
-            if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+            if (timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
             s.last_wg = n_chunks;
             s.last_f = emit;
             continue;
@@ -1105,8 +1157,8 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
             a.accumulate = b == first_launch ? 0 : 1;
             const long long slots = (long long)p->n_cu * zoom_resident(s, true);
-            if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
-            const bool split = p->timing && 2 * (long long)launches.size() - 1 <= kMidEvents;
+            if (timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+            const bool split = timing && 2 * (long long)launches.size() - 1 <= kMidEvents;
             int n_mid = 0;
             hipEvent_t* mid = s.ring_mid.data() + (size_t)slot * kMidEvents;
             int n_launches = 0;
@@ -1191,13 +1243,13 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                     s.fill_slots_a = (int)slots;
                 }
                 if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
-                s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
+                if (!dry) s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
                 if (split) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
-                s.zoom->synthesis(a, groups, p->stream);
+                if (!dry) s.zoom->synthesis(a, groups, p->stream);
                 ++n_launches;
             }
-            if (p->timing) s.ring_mid_n[slot] = n_mid;
-            if (n_lr_total > 1 || n_c_total > 1) {
+            if (timing) s.ring_mid_n[slot] = n_mid;
+            if (!dry && (n_lr_total > 1 || n_c_total > 1)) {
                 if (seam_vec_ok(p, d_c, d_l, d_r, s.hop) && n_lr_total + n_c_total <= 65535)
                     hipLaunchKernelGGL(upx_zoom_seam_add4_kernel, dim3((unsigned)((tail / 4 + 255) / 256), (unsigned)(n_lr_total + n_c_total)),
                                        dim3(256), 0, p->stream, a, (int)n_lr_total, (int)n_c_total, (int)tail);
@@ -1205,7 +1257,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                     hipLaunchKernelGGL(upx_zoom_seam_add_kernel, dim3(grid_for((n_lr_total + n_c_total) * tail)), dim3(256), 0,
                                        p->stream, a, (int)n_lr_total, (int)n_c_total, (int)tail);
             }
-            if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+            if (timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
             s.last_wg = (int)((n_lr_total + n_c_total) * groups);
             s.last_f = tab_lr[1] - tab_lr[0];
             continue;
@@ -1309,9 +1361,9 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         s.fill_wg = (int)n_wg;
         s.fill_slots = (int)slots;
         s.fill_wg_a = s.fill_slots_a = 0;
-        if (p->timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
-        s.kern->launch(a, (int)n_wg, p->stream);
-        if (n_streams > 1) {
+        if (timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+        if (!dry) s.kern->launch(a, (int)n_wg, p->stream);
+        if (!dry && n_streams > 1) {
             if (seam_vec_ok(p, d_c, d_l, d_r, s.hop) && n_streams <= 65535)
                 hipLaunchKernelGGL(upx_stream_seam_add4_kernel, dim3((unsigned)((tail / 4 + 255) / 256), (unsigned)n_streams), dim3(256), 0,
                                    p->stream, a, (int)n_streams, (int)tail, s.hop);
@@ -1319,14 +1371,26 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
                 hipLaunchKernelGGL(upx_stream_seam_add_kernel, dim3(grid_for(n_streams * tail)), dim3(256), 0, p->stream, a,
                                    (int)n_streams, (int)tail, s.hop);
         }
-        if (p->timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+        if (timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
     }
     HIP_TRY(hipGetLastError());
+    if (dry) return UPX_OK;
     p->timed_once = p->timing;
     if (p->timing) {
         for (auto& s : p->bands) s.ring_used[slot] = s.last_wg > 0;
         p->timed_calls += 1;
     }
+    return UPX_OK;
+}
+
+int upx_plan_reserve(upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out) {
+    if (!p || t_in < 0 || own_len < 0 || t_out < 0) return fail(UPX_ERR_INVALID, "upx_plan_reserve: bad argument");
+    if (t_out == 0) return UPX_OK;
+    p->dry_run = true;
+    const int rc = upx_process_device(p, nullptr, t_in, own_len, nullptr, nullptr, nullptr, t_out);
+    p->dry_run = false;
+    if (rc != UPX_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(p->stream));   // the table uploads have landed: the first real call finds nothing left to do
     return UPX_OK;
 }
 
@@ -1350,6 +1414,11 @@ namespace {
 // One work item of a streamed host call: a chunk of a track (or a whole short track).
 struct PipeItem {
     const float* src = nullptr;          // host stereo, first sample of the item
+    // upx_process_lr: the caller's own arrays go up as they are and are cast / interleaved on the device.  fmt =
+    // UPX_SAMPLE_F32 / _F64; src_r == nullptr: `src` is interleaved [t_in][2] of fmt; else `src` / `src_r` are the
+    // contiguous left / right arrays.  (plain float32 interleaved input: fmt = F32, src_r = nullptr, no convert pass)
+    const void* src_r = nullptr;
+    int fmt = UPX_SAMPLE_F32;
     int64_t t_in = 0, own = 0, t_out = 0;   // samples uploaded, samples whose frames are owned, output plane length
     float* dst[3] = {nullptr, nullptr, nullptr};   // host planes at the item's first owned sample
     int64_t seam = 0;                    // > 0: add this many spill samples of the previous item (same track) ...
@@ -1359,8 +1428,12 @@ struct PipeItem {
 // Cuts one track into items exactly as upx_process does on its own (so a batch equals per-track calls bit for
 // bit): chunks of `chunk` owned samples on the shard grid when the track is long enough, else one item.
 int items_of_track(const upx_plan* p, const float* stereo, int64_t n, float* out_c, float* out_l, float* out_r,
-                   int64_t chunk, bool force_chunks, std::vector<PipeItem>& items) {
+                   int64_t chunk, bool force_chunks, std::vector<PipeItem>& items, const void* right = nullptr,
+                   int fmt = UPX_SAMPLE_F32) {
     if (n == 0) return UPX_OK;
+    // bytes from one sample of `stereo` (and of `right`) to the next
+    const size_t elem = fmt == UPX_SAMPLE_F64 ? 8 : 4, step = right ? elem : 2 * elem;
+    const size_t first_item = items.size();
     int64_t grid = 0, spill = 0;
     const bool gridded = shard_geometry(p, &grid, &spill);
     bool cut = chunk > 0 && gridded && (force_chunks || (n >= 2 * chunk && chunk >= 4 * spill));
@@ -1372,6 +1445,7 @@ int items_of_track(const upx_plan* p, const float* stereo, int64_t n, float* out
     if (!cut) {
         PipeItem it;
         it.src = stereo; it.t_in = n; it.own = n; it.t_out = n;
+        it.src_r = right; it.fmt = fmt;
         it.dst[0] = out_c; it.dst[1] = out_l; it.dst[2] = out_r;
         items.push_back(it);
         return UPX_OK;
@@ -1385,7 +1459,9 @@ int items_of_track(const upx_plan* p, const float* stereo, int64_t n, float* out
         const int64_t start = i * own;
         const bool last = i == n_chunks - 1;
         PipeItem it;
-        it.src = stereo + 2 * start;
+        it.src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(stereo) + (size_t)start * step);
+        it.src_r = right ? reinterpret_cast<const char*>(right) + (size_t)start * step : nullptr;
+        it.fmt = fmt;
         it.own = last ? n - start : own;
         it.t_in = n - start < it.own + spill ? n - start : it.own + spill;
         it.t_out = last ? it.own : it.own + spill;
@@ -1396,6 +1472,7 @@ int items_of_track(const upx_plan* p, const float* stereo, int64_t n, float* out
         }
         items.push_back(it);
     }
+    (void)first_item;
     return UPX_OK;
 }
 
@@ -1418,6 +1495,29 @@ int run_items(upx_plan* p, const std::vector<PipeItem>& items) {
         if (it.t_out > cap_out) cap_out = it.t_out;
     }
     const size_t in_floats = (size_t)cap_in * 2, out_floats = (size_t)cap_out * 3;
+    // items whose samples are cast / interleaved on the device land in a raw buffer first (two sets like the others)
+    size_t raw_bytes = 0;
+    for (const auto& it : items)
+        if (it.src_r || it.fmt != UPX_SAMPLE_F32) {
+            const size_t b = (size_t)it.t_in * 2 * (it.fmt == UPX_SAMPLE_F64 ? 8 : 4);
+            if (b > raw_bytes) raw_bytes = b;
+        }
+    if (raw_bytes > p->pipe_raw_bytes) {
+        HIP_TRY(hipDeviceSynchronize());
+        for (int i = 0; i < 2; ++i) {
+            if (p->d_pipe_raw[i]) HIP_TRY(hipFree(p->d_pipe_raw[i]));
+            p->d_pipe_raw[i] = nullptr;
+        }
+        p->pipe_raw_bytes = 0;
+        for (int i = 0; i < (items.size() > 1 ? 2 : 1); ++i) {
+            hipError_t e = hipMalloc(&p->d_pipe_raw[i], raw_bytes);
+            if (e != hipSuccess) return fail(UPX_ERR_NOMEM, "hipMalloc(%zu) for a work item's raw samples: %s", raw_bytes, hipGetErrorString(e));
+        }
+        p->pipe_raw_bytes = raw_bytes;
+    } else if (raw_bytes > 0 && items.size() > 1 && !p->d_pipe_raw[1]) {
+        hipError_t e = hipMalloc(&p->d_pipe_raw[1], p->pipe_raw_bytes);
+        if (e != hipSuccess) return fail(UPX_ERR_NOMEM, "hipMalloc(%zu) for a work item's raw samples: %s", p->pipe_raw_bytes, hipGetErrorString(e));
+    }
     // two rotating buffer sets, grown on demand and never shrunk; a call with ONE work item (a short signal, or
     // UPX_STREAM_CHUNK=0) only touches - and only ever allocates - the first.  Both sets share one plane pitch.
     const int n_sets = items.size() > 1 ? 2 : 1;
@@ -1456,9 +1556,27 @@ int run_items(upx_plan* p, const std::vector<PipeItem>& items) {
     auto submit = [&](int64_t i, std::string& msg) -> int {
         const PipeItem& it = items[(size_t)i];
         const int b = (int)(i & 1);
-        hipError_t e = hipMemcpyAsync(p->d_pipe_in[b], it.src, (size_t)it.t_in * 2 * sizeof(float), hipMemcpyHostToDevice, p->s_h2d);
+        const bool raw = it.src_r || it.fmt != UPX_SAMPLE_F32;
+        const size_t elem = it.fmt == UPX_SAMPLE_F64 ? 8 : 4;
+        hipError_t e;
+        if (!raw) {
+            e = hipMemcpyAsync(p->d_pipe_in[b], it.src, (size_t)it.t_in * 2 * sizeof(float), hipMemcpyHostToDevice, p->s_h2d);
+        } else if (!it.src_r) {
+            e = hipMemcpyAsync(p->d_pipe_raw[b], it.src, (size_t)it.t_in * 2 * elem, hipMemcpyHostToDevice, p->s_h2d);
+        } else {
+            char* d = static_cast<char*>(p->d_pipe_raw[b]);
+            e = hipMemcpyAsync(d, it.src, (size_t)it.t_in * elem, hipMemcpyHostToDevice, p->s_h2d);
+            if (e == hipSuccess) e = hipMemcpyAsync(d + (size_t)it.t_in * elem, it.src_r, (size_t)it.t_in * elem, hipMemcpyHostToDevice, p->s_h2d);
+        }
         if (e == hipSuccess) e = hipEventRecord(p->ev_h2d[b], p->s_h2d);
         if (e == hipSuccess) e = hipStreamWaitEvent(p->stream, p->ev_h2d[b], 0);
+        if (e == hipSuccess && raw) {
+            // the cast is the host's: round to nearest even, beyond the float32 range to infinity (numpy's astype)
+            hipLaunchKernelGGL(upx_samples_to_stereo_kernel, dim3(grid_for(it.t_in)), dim3(256), 0, p->stream, p->d_pipe_raw[b],
+                               it.fmt == UPX_SAMPLE_F64 ? 1 : 0, it.src_r ? 1 : 0, (long long)it.t_in,
+                               reinterpret_cast<float2*>(p->d_pipe_in[b]));
+            e = hipGetLastError();
+        }
         if (e != hipSuccess) {
             msg = std::string("upload of a work item failed: ") + hipGetErrorString(e);
             return UPX_ERR_HIP;
@@ -1528,6 +1646,25 @@ int upx_process(upx_plan* p, const float* stereo, int64_t n, float* out_c, float
     // length); short ones are a single work item of the same pipeline
     std::vector<PipeItem> items;
     if (int rc = items_of_track(p, stereo, n, out_c, out_l, out_r, stream_chunk_default(p), false, items)) return rc;
+    return run_items(p, items);
+}
+
+int upx_process_lr(upx_plan* p, const void* left, const void* right, int sample_format, int64_t stride, int64_t n,
+                   float* out_c, float* out_l, float* out_r) {
+    if (!p || n < 0) return fail(UPX_ERR_INVALID, "upx_process_lr: bad argument");
+    if (sample_format != UPX_SAMPLE_F32 && sample_format != UPX_SAMPLE_F64)
+        return fail(UPX_ERR_INVALID, "upx_process_lr: sample_format %d (UPX_SAMPLE_F32 or UPX_SAMPLE_F64)", sample_format);
+    if (n == 0) return UPX_OK;
+    if (!left || !right || !out_c || !out_l || !out_r) return fail(UPX_ERR_INVALID, "upx_process_lr: NULL buffer");
+    const size_t elem = sample_format == UPX_SAMPLE_F64 ? 8 : 4;
+    const bool interleaved = stride == 2 && static_cast<const char*>(right) == static_cast<const char*>(left) + elem;
+    if (!interleaved && stride != 1)
+        return fail(UPX_ERR_UNSUPPORTED, "upx_process_lr: stride %lld (1 = two contiguous arrays; 2 with right == left + one "
+                                         "element = the columns of one interleaved [T][2] array)", (long long)stride);
+    std::vector<PipeItem> items;
+    if (int rc = items_of_track(p, static_cast<const float*>(left), n, out_c, out_l, out_r, stream_chunk_default(p), false,
+                                items, interleaved ? nullptr : right, sample_format))
+        return rc;
     return run_items(p, items);
 }
 

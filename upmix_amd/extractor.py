@@ -72,12 +72,49 @@ class DevicePlan:
         if x.ndim != 2 or x.shape[1] != 2:
             raise ValueError("stereo must have shape [T, 2]")
         total = x.shape[0]
-        out = [self.host_empty(total, np.float32) for _ in range(3)]   # pooled page-locked memory (hostmem.py)
+        out = self._result_planes(total)
         if total == 0:
             return tuple(out)
         # any length: the library streams long signals through the device in chunks (upx_process_chunked)
         with self.lock:
             _lib.check(self._lib.upx_process(self.handle, _f32p(x), total, *(_f32p(o) for o in out)))
+        return tuple(out)
+
+    def _result_planes(self, total: int):
+        """Three float32[total] result arrays: pooled page-locked memory from the second call on that asks for this size,
+        plain NumPy arrays on the first (hostmem.PinnedPool.take: a one-shot process must not pay for pinning)."""
+        token = hostmem.POOL.new_call()
+        return [hostmem.empty(total, np.float32, self.handle, lazy=token) for _ in range(3)]
+
+    def process_lr(self, L, R) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """
+        (L, R) as the reference's callers hold them -> (center, left, right) float32[T]: center_extraction.py:477-482 takes
+        any two real arrays, and main.py:49-50, 78-80 passes two float64 COLUMN VIEWS of one [T, 2] array.  float32 /
+        float64 arrays that are such a pair of columns, or contiguous each, go to the library as they are (upx_process_lr:
+        cast and interleave on the device, bit-identical to the host cast); anything else (other dtypes, other strides,
+        unequal dtypes) is cast and interleaved here first, as before.
+        """
+        a, b = np.asarray(L), np.asarray(R)
+        if a.ndim != 1 or b.ndim != 1:
+            raise ValueError("L and R must be one-dimensional")
+        if a.shape[0] != b.shape[0]:
+            # (the reference pads each to whole frames on its own and fails in the band sum; say so up front)
+            raise ValueError(f"L and R differ in length ({a.shape[0]} vs {b.shape[0]})")
+        total = a.shape[0]
+        fmt = {np.dtype(np.float32): _lib.SAMPLE_F32, np.dtype(np.float64): _lib.SAMPLE_F64}.get(a.dtype)
+        stride = 0
+        if fmt is not None and b.dtype == a.dtype and a.dtype.isnative and total > 0:
+            size = a.dtype.itemsize
+            if a.strides[0] == 2 * size and b.strides[0] == 2 * size and b.ctypes.data == a.ctypes.data + size:
+                stride = 2
+            elif (a.strides[0] == size or total == 1) and (b.strides[0] == size or total == 1):
+                stride = 1
+        if stride == 0:
+            return self.process(np.stack([np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)], axis=1))
+        out = self._result_planes(total)
+        with self.lock:
+            _lib.check(self._lib.upx_process_lr(self.handle, C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data), fmt,
+                                                stride, total, *(_f32p(o) for o in out)))
         return tuple(out)
 
     def process_tracks(self, tracks: Sequence[np.ndarray]) -> List[Tuple[np.ndarray, np.ndarray, np.ndarray]]:
@@ -91,7 +128,8 @@ class DevicePlan:
             if x.ndim != 2 or x.shape[1] != 2:
                 raise ValueError("every track must have shape [T, 2]")
         n = len(xs)
-        outs = [[self.host_empty(x.shape[0], np.float32) for _ in range(3)] for x in xs]
+        token = hostmem.POOL.new_call()
+        outs = [[hostmem.empty(x.shape[0], np.float32, self.handle, lazy=token) for _ in range(3)] for x in xs]
         if n == 0:
             return []
         lens = (C.c_int64 * n)(*[x.shape[0] for x in xs])
@@ -107,7 +145,7 @@ class DevicePlan:
         if x.ndim != 2 or x.shape[1] != 2:
             raise ValueError("stereo must have shape [T, 2]")
         total = x.shape[0]
-        out = [self.host_empty(total, np.float32) for _ in range(3)]
+        out = self._result_planes(total)
         if total:
             with self.lock:
                 _lib.check(self._lib.upx_process_chunked(self.handle, _f32p(x), total, *(_f32p(o) for o in out), int(chunk)))
@@ -144,6 +182,12 @@ class DevicePlan:
     def process_device(self, d_in: int, t_in: int, own_len: int, d_c: int, d_l: int, d_r: int, t_out: int) -> None:
         _lib.check(self._lib.upx_process_device(self.handle, C.c_void_p(d_in), int(t_in), int(own_len),
                                                 C.c_void_p(d_c), C.c_void_p(d_l), C.c_void_p(d_r), int(t_out)))
+
+    def reserve(self, t_in: int, own_len: int, t_out: int) -> None:
+        """Everything the first process_device call of this shape would allocate / upload / synchronise for, up front
+        (upx_plan_reserve): the call itself then only enqueues kernels."""
+        with self.lock:
+            _lib.check(self._lib.upx_plan_reserve(self.handle, int(t_in), int(own_len), int(t_out)))
 
     def enable_timing(self, on: bool = True) -> None:
         _lib.check(self._lib.upx_plan_enable_timing(self.handle, 1 if on else 0))
@@ -436,8 +480,7 @@ class MultiBandExtractorAccu:
 
     def process_all_blocks(self, L: np.ndarray, R: np.ndarray) -> tuple:
         """Whole-signal band output (c, l, r), float32, length len(L).  center_extraction.py:426-472"""
-        return self._device_plan().process(np.stack([np.asarray(L, dtype=np.float32),
-                                                     np.asarray(R, dtype=np.float32)], axis=1))
+        return self._device_plan().process_lr(L, R)
 
     def process_stereo_chunk(self, blkL: np.ndarray, blkR: np.ndarray) -> tuple:
         """
@@ -518,9 +561,10 @@ def extract_center_left_right_multi_band_in_memory(L: np.ndarray, R: np.ndarray,
     the reference (center_extraction.py:477-513).  Thread-safe (the reference's own caller
     is a thread pool): distinct band lists run on distinct plans, equal ones take turns.
     """
-    stereo = np.stack([np.asarray(L, dtype=np.float32), np.asarray(R, dtype=np.float32)], axis=1)
+    # (L, R) go to the library as the caller holds them - main.py:49-50 hands two float64 column views of one [T, 2]
+    # array - and are cast / interleaved on the device (DevicePlan.process_lr)
     with _checked_out_plan(band_extractors, device) as plan:
-        return plan.process(stereo)
+        return plan.process_lr(L, R)
 
 
 def process_tracks(tracks: Sequence[np.ndarray], band_extractors: List[MultiBandExtractorAccu], *,

@@ -54,18 +54,41 @@ class PinnedPool:
         self._plan_handle = None  # any live upx_plan of the process (allocation needs a device context)
         self.closed = False
         self.plans_live = True    # False between the close of the process' last plan and the creation of the next one
+        # lazy pinning (take(lazy=token)): capacity -> the call that first asked for a block of it
+        self._asked: Dict[int, int] = {}
+        self._calls = 0
+        self._libref = None       # the loaded library (bound on first use: the sweeper must not look it up at shutdown)
+        self._sweeper = None      # thread that unpins blocks which come back while no plan is alive (trim)
 
-    def take(self, nbytes: int, plan_handle) -> np.ndarray:
-        """uint8[nbytes] in page-locked memory; plain pageable memory if the pool is at its limit or pinning fails."""
+    def new_call(self) -> int:
+        """Token of one host-buffer call (DevicePlan.process ...): its result arrays are requested with lazy=token."""
+        with self._lock:
+            self._calls += 1
+            return self._calls
+
+    def take(self, nbytes: int, plan_handle, lazy: int = 0) -> np.ndarray:
+        """
+        uint8[nbytes] in page-locked memory; plain pageable memory if the pool is at its limit or pinning fails.
+
+        lazy = a new_call() token: pinning a block costs ~0.25 ms per MiB (92 ms for the three result planes of 10 min of
+        audio against 41 ms for the whole call into pageable arrays), which only pays when the block is used again.  The
+        reference's flow is ONE call per process (main.py:78-80), so the FIRST call that asks for a capacity gets pageable
+        arrays (what the reference returns, center_extraction.py:503-513); a later call that asks for the same capacity
+        has proven reuse and pins.  Idle blocks of the right capacity are always used.
+        """
         nbytes = int(nbytes)
         if nbytes <= 0 or self.closed or self.limit <= 0:
             return np.empty(max(nbytes, 0), dtype=np.uint8)
         cap = -(-nbytes // _GRANULE) * _GRANULE
-        lib = _lib.load()
+        lib = self._libref = self._libref or _lib.load()
         with self._lock:
             self._collect()
             stack = self._free.get(cap)
             ptr = stack.pop() if stack else None
+            if ptr is None and lazy:
+                first = self._asked.setdefault(cap, lazy)
+                if first == lazy:
+                    return np.empty(nbytes, dtype=np.uint8)
             if ptr is None:
                 # make room by releasing idle blocks of other sizes before giving up
                 while self._held + cap > self.limit and any(self._free.values()):
@@ -86,16 +109,10 @@ class PinnedPool:
         return np.asarray(_Lease(self, ptr, cap, nbytes))
 
     def _give_back(self, ptr: int, cap: int) -> None:
-        if not self.plans_live and not self.closed and not sys.is_finalizing():
-            # a result that outlived every plan: nothing will ask the pool for memory again soon, so the block is
-            # unpinned now instead of staying page-locked for the rest of the process (upx_host_free takes no plan then)
-            try:
-                if _lib.load().upx_host_free(None, C.c_void_p(ptr)) == _lib.UPX_OK:
-                    self._held -= cap      # (int update under the GIL; take() re-reads it under its lock)
-                    return
-            except Exception:              # interpreter teardown, library gone: the runtime frees it at unload
-                pass
-        self._returned.append((ptr, cap))   # (a closed pool keeps them: the runtime frees the blocks at unload)
+        # Runs in a finaliser, i.e. at any allocation point of any thread: append only.  No lock, no accounting and above
+        # all no runtime call here (hipHostFree synchronises the device); take(), trim() and the sweeper thread do all of
+        # that under the pool's lock.
+        self._returned.append((ptr, cap))
 
     def _collect(self) -> None:
         """Move returned blocks to the free lists (call with the lock held)."""
@@ -106,16 +123,46 @@ class PinnedPool:
                 return
             self._free.setdefault(cap, []).append(ptr)
 
+    def _release_idle(self, plan_handle) -> None:
+        """Unpin every idle block (call with the lock held).  plan_handle None: page-locked memory is not tied to a device."""
+        lib = self._libref = self._libref or _lib.load()
+        self._collect()
+        for cap, stack in self._free.items():
+            while stack:
+                if lib.upx_host_free(plan_handle, C.c_void_p(stack.pop())) == _lib.UPX_OK:
+                    self._held -= cap
+
+    def _sweep(self) -> None:
+        # Between the close of the process' last plan and the next plan: results that outlived every plan come back one by
+        # one; nothing will ask the pool for memory soon, so they are unpinned as they arrive instead of staying page-locked
+        # for the rest of the process.  Ends when nothing is leased any more, a plan exists again or the pool is closed.
+        import time
+        while True:
+            time.sleep(0.25)
+            if sys.is_finalizing():
+                return
+            with self._lock:
+                if self.plans_live or self.closed:
+                    self._sweeper = None
+                    return
+                try:
+                    self._release_idle(None)
+                except Exception:      # library gone: the runtime frees the blocks at unload
+                    self._sweeper = None
+                    return
+                if self._held <= 0:
+                    self._sweeper = None
+                    return
+
     def trim(self, plan_handle) -> None:
         """Release every idle block (called when the last plan closes, while a device context still exists)."""
-        lib = _lib.load()
         with self._lock:
-            self._collect()
-            for cap, stack in self._free.items():
-                while stack:
-                    lib.upx_host_free(plan_handle, C.c_void_p(stack.pop()))
-                    self._held -= cap
+            self._release_idle(plan_handle)
             self.plans_live = False     # (DevicePlan.close calls this for the process' last plan)
+            self._asked.clear()
+            if self._held > 0 and self._sweeper is None and not self.closed:
+                self._sweeper = threading.Thread(target=self._sweep, name="upx-pinned-pool-sweeper", daemon=True)
+                self._sweeper.start()
 
     def close(self) -> None:
         with self._lock:
@@ -157,9 +204,9 @@ def _limit_from_env() -> int:
 POOL = PinnedPool(_limit_from_env())
 
 
-def empty(nbytes_or_shape, dtype, plan_handle) -> np.ndarray:
-    """np.empty(shape, dtype) in pooled page-locked memory."""
+def empty(nbytes_or_shape, dtype, plan_handle, lazy: int = 0) -> np.ndarray:
+    """np.empty(shape, dtype) in pooled page-locked memory (lazy = POOL.new_call() token: see PinnedPool.take)."""
     shape = (nbytes_or_shape,) if np.isscalar(nbytes_or_shape) else tuple(nbytes_or_shape)
     dt = np.dtype(dtype)
     n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
-    return POOL.take(n, plan_handle).view(dt).reshape(shape)
+    return POOL.take(n, plan_handle, lazy).view(dt).reshape(shape)
