@@ -457,7 +457,8 @@ def main():
                     pass
             comm = _HostSeam()
         elif world > 1:
-            comm = sharding.RcclSeam(plan, rank, world, broadcast=group.broadcast_bytes)
+            comm = sharding.RcclSeam(plan, rank, world, broadcast=group.broadcast_bytes, all_ok=group.all_ok)
+            _lib.check(_lib.load().upx_comm_reserve(comm.handle, spill))   # the seam buffer up front, not inside the first step
 
         def step():
             plan.process_device(d_in, t_in, own, d_out[0], d_out[1], d_out[2], t_out)
@@ -466,6 +467,8 @@ def main():
         calls_per_step = 1
 
     def barrier():
+        if hasattr(comm, "wait"):
+            comm.wait()      # bounded: a peer that never entered the all-reduce aborts the communicator instead of hanging the sync
         plan.sync()
         group.barrier()
 
@@ -502,6 +505,8 @@ def main():
         plan.pause_timing(not sampled)
         timed_steps += sampled
         step()
+    if hasattr(comm, "wait"):
+        comm.wait()
     plan.sync()
     group.barrier()
     elapsed = group.allreduce_max([time.perf_counter() - t0])[0]    # the slowest rank's time

@@ -294,6 +294,21 @@ void upx_comm_destroy(upx_comm* comm);
  * own_len == 0 ranks are not supported.
  */
 int upx_comm_seam_exchange(upx_comm* comm, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill);
+/*
+ * Failure containment between ranks.  A collective has no error path of its own: a rank whose peer never enters the
+ * all-reduce waits in hipStreamSynchronize for ever.  The reference fails with plain exceptions (main.py:40-41,
+ * center_extraction.py:91-92); here the ranks first VOTE over their process group (upmix_amd.rendezvous.all_ok) before
+ * every collective, and what a vote cannot catch - a peer that dies inside the collective - ends in an abort:
+ *   upx_comm_wait     waits for the last queued seam exchange; when `timeout_s` (< 0: UPX_COMM_TIMEOUT, else
+ *                     UPX_RDZV_TIMEOUT, else 600 s) runs out, or RCCL reports an asynchronous error, the communicator is
+ *                     aborted and UPX_ERR_RCCL returned.  upx_wav_shard_seal calls it before it synchronises.
+ *   upx_comm_abort    ncclCommAbort: the communicator's kernels leave, the communicator is gone (idempotent); every later
+ *                     call on it fails.  The process is expected to exit non-zero - a fresh process is the only restart.
+ *   upx_comm_reserve  allocates the seam buffer for `spill` up front (otherwise inside the first exchange).
+ */
+int upx_comm_wait(upx_comm* comm, double timeout_s);
+int upx_comm_abort(upx_comm* comm);
+int upx_comm_reserve(upx_comm* comm, int64_t spill);
 /* Samples of the predecessor's spill that upx_comm_seam_exchange adds onto the head of `rank`: `spill`, except on the
    LAST rank, whose planes may end at own_len < spill (sharding.ShardGeometry.plan only keeps shards with a successor
    at least `spill` long; the rest of the spill lies past the signal's end); 0 for rank 0.  Pure arithmetic, no GPU. */

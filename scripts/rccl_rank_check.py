@@ -22,7 +22,7 @@ def mapped(pattern):
 group = Rendezvous.from_env()
 bands = ux.chain_bands([0, 300, 3000], 0.75, ux.make_blackman_harris, 48000, max_block_size=1024, verbose=False, device=0)
 plan = ux.DevicePlan(bands, device=0)
-seam = sharding.RcclSeam(plan, group.rank, group.world, broadcast=group.broadcast_bytes)
+seam = sharding.RcclSeam(plan, group.rank, group.world, broadcast=group.broadcast_bytes, all_ok=group.all_ok)
 print("librccl mapped:", mapped("librccl"))
 print("libamdhip64 mapped:", mapped("libamdhip64"))
 print("torch imported:", "torch" in sys.modules)

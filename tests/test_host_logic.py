@@ -161,3 +161,34 @@ def test_gain_vectors_of_band_edge_corner_cases_bit_exact():
     for tag, (n, lo, hi, mode, wl, wh) in EDGE_BANDS.items():
         g = ux.band_limit_gain(n, 48000, lo, hi, mode, wl, wh)
         assert g.dtype == np.float64 and np.array_equal(g, z[f"{tag}_gain"]), tag
+
+
+def test_long_files_fall_back_to_the_host_flow_when_the_plan_cannot_chunk(tmp_path, monkeypatch):
+    """Round-4 advisor finding: files of 2^29 frames or more abort in upx_wav_shard_open (UPX_ERR_INVALID) when the plan's
+    hops share no shard grid or UPX_WAV_CHUNK=0; cli / batch must check first and take the host flow."""
+    from upmix_amd import cli
+
+    class Band:
+        def __init__(self, hop):
+            self.hop_size = hop
+    pow2 = [Band(2048), Band(1024), Band(64)]
+    odd = [Band(2048), Band(204)]                      # overlap 0.6 at N = 512: hop 204 divides nothing
+    assert cli.codec_can_take(cli.LAUNCH_FRAMES - 1, odd, {})
+    assert cli.codec_can_take(cli.LAUNCH_FRAMES, pow2, {}) and cli.codec_can_take(10 * cli.LAUNCH_FRAMES, pow2, {"UPX_WAV_CHUNK": "4194304"})
+    assert not cli.codec_can_take(cli.LAUNCH_FRAMES, odd, {})
+    assert not cli.codec_can_take(cli.LAUNCH_FRAMES, pow2, {"UPX_WAV_CHUNK": "0"})
+    # run() falls through to the host flow when the codec declines (a short file + a lowered launch limit stand in for 2^29 frames)
+    import numpy as np
+    from upmix_amd import wav
+    os.makedirs(tmp_path / "in")
+    wav.write(str(tmp_path / "in" / "a.wav"), np.zeros((5000, 2)), 48000, "PCM_16")
+    monkeypatch.setattr(cli, "LAUNCH_FRAMES", 1000)
+    monkeypatch.setenv("UPX_WAV_CHUNK", "0")
+    monkeypatch.setattr(cli, "chain_bands", lambda *a, **k: [Band(256), Band(64)])
+
+    def host_extract(L, R, sr, bands, device=0):
+        assert L.shape == (5000,) and [b.hop_size for b in bands] == [256, 64]
+        raise RuntimeError("host flow reached")
+    monkeypatch.setattr(cli, "extract_center_left_right_multi_band_in_memory", host_extract)
+    with pytest.raises(RuntimeError, match="host flow reached"):
+        cli.run("a.wav", "stereo_sum", str(tmp_path / "in"), str(tmp_path / "out"))

@@ -340,3 +340,98 @@ def test_streamed_file_to_file_in_pieces(tmp_path, monkeypatch):
         for d in ("one", "cut"):
             for name in os.listdir(os.path.join(tmp, d)):
                 os.remove(os.path.join(tmp, d, name))
+
+
+# ---- failure containment between ranks (round 5) ------------------------------------------------------------------------
+class _FakePlan:
+    """Stand-in for DevicePlan on the streamed device flow of run_rank: rank `fail_rank`'s feed raises (an I/O error in a
+    reader thread, UPX_ERR_NOMEM ...); a seal that is reached stands for the seam all-reduce a peer never enters: it would
+    block for a minute."""
+    sealed = False
+
+    def __init__(self, rank, fail_rank, where):
+        self.rank, self.fail_rank, self.where = rank, fail_rank, where
+        if where == "plan" and rank == fail_rank:
+            raise MemoryError("hipMalloc(12345): out of memory")
+
+    def host_empty(self, n, dtype=np.uint8):
+        return np.empty(n, dtype=dtype)
+
+    def wav_shard_open(self, *a, **k):
+        pass
+
+    def wav_shard_feed(self, pcm, n):
+        if self.where == "feed" and self.rank == self.fail_rank:
+            raise OSError("read error in a reader thread")
+
+    def wav_shard_seal(self):
+        import time
+        type(self).sealed = True
+        time.sleep(60)          # the collective nobody leaves
+        return 0.0, 0.0
+
+    def close(self):
+        pass
+
+
+class _FakeSeam:
+    def __init__(self, plan, rank, world, broadcast=None, all_ok=None):
+        all_ok(True, "")                      # RcclSeam votes before and after RCCL's blocking init
+        broadcast(b"id" if rank == 0 else None)
+        all_ok(True, "")
+
+    def close(self):
+        pass
+
+
+def _containment_worker(rank, world, port, tmp, where, q):
+    import time
+    from upmix_amd.rendezvous import Rendezvous, RendezvousError
+    group = Rendezvous(rank, world, "127.0.0.1", port, timeout=30)
+    bands = oracle_bands()
+    t0 = time.monotonic()
+    try:
+        multi_gpu.run_rank(os.path.join(tmp, "in", "song.wav"), os.path.join(tmp, "out"), "stereo_sum", bands, 0.75, "PCM_16",
+                           rank, world, group, log=lambda *_: None,
+                           plan_factory=lambda b, d: _FakePlan(rank, 1, where), seam_factory=_FakeSeam)
+        outcome = ("returned", "")
+    except RendezvousError as exc:
+        outcome = ("RendezvousError", str(exc))
+    except Exception as exc:   # noqa: BLE001
+        outcome = (type(exc).__name__, str(exc))
+    q.put((rank, outcome, time.monotonic() - t0, _FakePlan.sealed))
+    group.close()
+
+
+@pytest.mark.parametrize("where", ["feed", "plan"])
+def test_a_failing_rank_does_not_leave_its_peer_in_the_collective(tmp_path, where):
+    """
+    Round-4 review: run_rank voted only AFTER wav_shard_seal, which contains the seam all-reduce - a rank that raised between
+    open and seal left its peers inside a collective with no error path.  Now the ranks vote before every collective: rank 1
+    fails (in a feed / while creating its plan), rank 0 gets a RendezvousError that names rank 1 within the timeout and never
+    enters seal; rank 1 raises its own exception (the reference's behaviour: a plain exception, main.py:40-41).
+    """
+    import multiprocessing
+    os.makedirs(tmp_path / "in")
+    make_wav(str(tmp_path / "in" / "song.wav"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = multiprocessing.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_containment_worker, args=(r, 2, port, str(tmp_path), where, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, outcome, seconds, sealed = q.get(timeout=45)
+        got[rank] = (outcome, seconds, sealed)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (kind0, msg0), sec0, sealed0 = got[0]
+    (kind1, msg1), sec1, sealed1 = got[1]
+    assert kind0 == "RendezvousError" and "rank 1" in msg0, got[0]
+    assert ("read error" in msg0) if where == "feed" else ("out of memory" in msg0)
+    assert kind1 == ("OSError" if where == "feed" else "MemoryError"), got[1]
+    assert sec0 < 20 and sec1 < 20 and not sealed0 and not sealed1

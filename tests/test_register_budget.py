@@ -46,9 +46,22 @@ ZOOM = {
 
 
 def load_resources():
-    if not os.path.exists(RESOURCES):
-        import __graft_entry__ as ge
+    """kernel_resources.json is a build product (git-ignored).  Missing, or older than a kernel source (the numbers of another
+    build): rebuild when hipcc is there, skip with the reason when it is not - never fail the module, never check stale numbers."""
+    import glob
+    import shutil
+    import __graft_entry__ as ge
+    csrc = os.path.join(ROOT, "upmix_amd", "csrc")
+    sources = glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.hip")) + \
+        [os.path.join(ROOT, "include", "upmix_hip.h")]
+    stale = not os.path.exists(RESOURCES) or any(os.path.getmtime(s) > os.path.getmtime(RESOURCES) for s in sources)
+    if stale:
+        if not (os.path.exists(ge.HIPCC) or shutil.which("hipcc")):
+            pytest.skip("kernel_resources.json is " + ("missing" if not os.path.exists(RESOURCES) else "older than the kernel sources") +
+                        " and hipcc is not available to rebuild it")
         ge.build_hip()
+        if os.path.exists(RESOURCES):
+            os.utime(RESOURCES)       # (a build with nothing to recompile leaves the summary as it is: it is current)
     with open(RESOURCES) as fh:
         raw = json.load(fh)
     return {bench.canonical_kernel_name(k): v for k, v in raw.items()}

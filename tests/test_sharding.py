@@ -103,3 +103,29 @@ def test_two_rank_gloo_seam_reduce(tmp_path):
             g[int(z["start"]):int(z["start"]) + len(z[k])] = z[k]
     for g, r in zip(got, ref):
         assert rms(g.astype(np.float64) - r) < 1e-8
+
+
+def _stuck_in_a_collective(seconds):
+    import time
+    from upmix_amd import sharding as sh
+    with sh._Watchdog(seconds, "rank 0: ncclCommInitRank"):
+        time.sleep(60)      # stands for the blocking init a peer never joins
+
+
+def test_watchdog_ends_a_process_stuck_in_a_blocking_collective():
+    """RCCL's blocking init has no error path: when a peer never arrives, the watchdog ends the process (non-zero) instead of
+    letting it wait for ever; a body that returns in time cancels it."""
+    import multiprocessing
+    import time
+    from upmix_amd import sharding as sh
+    ctx = multiprocessing.get_context("spawn")
+    p = ctx.Process(target=_stuck_in_a_collective, args=(0.5,))
+    t0 = time.monotonic()
+    p.start()
+    p.join(30)
+    assert p.exitcode not in (0, None) and time.monotonic() - t0 < 25, p.exitcode
+    with sh._Watchdog(0.3, "quick"):
+        pass
+    time.sleep(0.6)         # cancelled: this process is still here
+    assert sh.comm_timeout({"UPX_COMM_TIMEOUT": "12.5", "UPX_RDZV_TIMEOUT": "3"}) == 12.5
+    assert sh.comm_timeout({"UPX_RDZV_TIMEOUT": "3"}) == 3.0 and sh.comm_timeout({}) == 600.0

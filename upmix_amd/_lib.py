@@ -87,6 +87,9 @@ SIGNATURES = {
     "upx_comm_create": (C.c_int, [vpp, C.c_void_p, C.c_int, C.c_int, C.c_char_p]),
     "upx_comm_destroy": (None, [C.c_void_p]),
     "upx_comm_seam_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64]),
+    "upx_comm_wait": (C.c_int, [C.c_void_p, C.c_double]),
+    "upx_comm_abort": (C.c_int, [C.c_void_p]),
+    "upx_comm_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
     "upx_comm_seam_add_len": (C.c_int64, [C.c_int, C.c_int, C.c_int64, C.c_int64]),
     "upx_comm_seam_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int,
                                          C.c_int]),

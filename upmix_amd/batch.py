@@ -27,7 +27,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
 
-from . import export, wav
+from . import cli, export, wav
 from .plan import WINDOW_FUNCS
 
 
@@ -124,7 +124,9 @@ def main(argv=None) -> int:
                         wav.device_kind(m, paths[i])
                     except ValueError:
                         return False
-                    return known_mode and not a.host_export and m["channels"] in (1, 2) and m["n_frames"] > 0
+                    # (files of 2^29 frames or more need a plan that can chunk: cli.codec_can_take; else the host flow)
+                    return (known_mode and not a.host_export and m["channels"] in (1, 2) and m["n_frames"] > 0 and
+                            cli.codec_can_take(m["n_frames"], bands))
 
                 def fetch(i):   # reader thread: the file's sample bytes, undecoded, into page-locked memory
                     m = metas[i]

@@ -50,9 +50,12 @@ def run(in_filename: str = "eyes.wav", export_mode: str = "stereo_sum", in_dir: 
         except ValueError:
             meta = None
         if meta is not None and meta["channels"] in (1, 2) and meta["n_frames"] > 0:
+          try:
             return _run_device_codec(meta, kind, int(meta["channels"]), int(meta["rate"]), int(meta["n_frames"]), in_path,
                                      base_in_name, export_mode, out_dir, band_edges, overlap, window, xover_mode, max_stft,
                                      threshold_factor, xo_fraction, device, subtype)
+          except _HostFlow:
+            pass       # a file the device codec cannot take in chunks: the NumPy flow below
     wave, sr = reader(in_path)
     print(f"Loaded '{in_path}', sr={sr}, shape={wave.shape}")
     if wave.ndim == 1:
@@ -90,6 +93,31 @@ def run(in_filename: str = "eyes.wav", export_mode: str = "stereo_sum", in_dir: 
 
 
 _SUBTYPE_KIND = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32, "FLOAT": 1032}
+LAUNCH_FRAMES = 1 << 29     # a launch indexes at most 2^29 - 1 frames; longer files go through the device in chunks
+
+
+class _HostFlow(Exception):
+    """The device codec cannot take this file: run() continues with the host flow."""
+
+
+def codec_can_take(n_frames: int, band_extractors, env=os.environ) -> bool:
+    """
+    Whether upx_wav_pipeline / upx_wav_shard_open accepts a file of n_frames: files of 2^29 frames or more run in chunks
+    on the plan's shard grid, which needs hops that share one (every hop divides the largest; overlaps that are not
+    powers of two do not) and the chunk schedule switched on (UPX_WAV_CHUNK != 0).  Otherwise the library answers
+    UPX_ERR_INVALID, and the callers take the host flow instead of aborting the run.
+    """
+    if n_frames < LAUNCH_FRAMES:
+        return True
+    hops = [int(b.hop_size) for b in band_extractors]
+    return all(max(hops) % h == 0 for h in hops) and str(env.get("UPX_WAV_CHUNK", "")).strip() != "0"
+
+
+def _print_plan(band_extractors) -> None:
+    """The per-band lines chain_bands prints (center_extraction.py:562-566), for a plan that was built quietly."""
+    for i, b in enumerate(band_extractors):
+        print(f"[Band {i+1}] f_low={b.f_low:.1f} Hz, f_high={b.f_high:.1f} Hz, block_size={b.block_size}, "
+              f"xover_low={b.xover_width_low_hz:.1f} Hz, xover_high={b.xover_width_high_hz:.1f} Hz")
 
 
 def _run_device_codec(meta, kind, channels, sr, n_frames, in_path, base_in_name, export_mode, out_dir, band_edges,
@@ -97,10 +125,13 @@ def _run_device_codec(meta, kind, channels, sr, n_frames, in_path, base_in_name,
     """Same flow with decode, peak scale, export layout and quantisation on the GPU (upx_wav_pipeline); the file's sample
     bytes are read, undecoded, straight into page-locked memory, so the chunks' uploads run beside their kernels."""
     from .extractor import DevicePlan
-    print(f"Loaded '{in_path}', sr={sr}, shape={(n_frames, channels) if channels > 1 else (n_frames,)}")
     band_extractors = chain_bands(list(band_edges), overlap, WINDOW_FUNCS[window], sr, xover_mode,
                                   max_block_size=max_stft, threshold_factor=threshold_factor,
-                                  xo_fraction=xo_fraction, device=device)
+                                  xo_fraction=xo_fraction, device=device, verbose=False)
+    if not codec_can_take(n_frames, band_extractors):
+        raise _HostFlow()
+    print(f"Loaded '{in_path}', sr={sr}, shape={(n_frames, channels) if channels > 1 else (n_frames,)}")
+    _print_plan(band_extractors)
     plan = DevicePlan(band_extractors, device)
     try:
         block = meta["bits"] // 8 * channels

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -442,6 +443,10 @@ struct upx_comm {
     int rank = 0, n_ranks = 1;
     float* d_seam = nullptr;
     long long seam_floats = 0;
+    hipEvent_t ev_done = nullptr;   // behind the last seam exchange on the plan's stream (upx_comm_wait)
+    bool pending = false;           // an exchange has been queued and not yet waited for
+    bool aborted = false;           // ncclCommAbort has run: the communicator is gone
+    double timeout_s = 600.0;       // UPX_COMM_TIMEOUT, else UPX_RDZV_TIMEOUT, else 600 s
 };
 
 namespace {
@@ -453,6 +458,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                        // optional
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;   // optional
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -472,6 +479,8 @@ int load_rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
+    r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
     r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.GetErrorString)
@@ -1917,6 +1926,8 @@ int upx_wav_shard_open(upx_plan* p, upx_comm* comm, int in_format, int channels,
     if (exchange && comm->rank + 1 < comm->n_ranks && t_out < own_len + spill)
         return fail(UPX_ERR_INVALID, "upx_wav_shard_open: planes of a shard with a successor need own_len + spill samples");
     HIP_TRY(hipSetDevice(p->device));
+    if (exchange)
+        if (int rc = upx_comm_reserve(comm, spill)) return rc;   // (not inside the exchange: that is a synchronising call)
     p->wav_t0 = wall_ms();
     p->wav_open = false;
     p->wav_feeding = false;
@@ -2046,8 +2057,11 @@ int upx_wav_shard_seal(upx_plan* p, double* peaks) {
     float* d_pl = (float*)p->d_wav[2];
     float* d_plane[3] = {d_pl, d_pl + p->wav_tout, d_pl + 2 * p->wav_tout};
     p->wav_feeding = false;
-    if (p->wav_comm)
+    if (p->wav_comm) {
         if (int rc = upx_comm_seam_exchange(p->wav_comm, d_plane[0], d_plane[1], d_plane[2], p->wav_own, p->wav_spill)) return rc;
+        // a peer that never enters the all-reduce must not hold this rank in the synchronisation below for ever
+        if (int rc = upx_comm_wait(p->wav_comm, -1.0)) return rc;
+    }
     if (p->wav_peaks_pending_head) {
         hipLaunchKernelGGL(upx_absmax3_kernel, dim3(grid_reduce(p->wav_head_own), 3), dim3(256), 0, st, d_plane[0], d_plane[1],
                            d_plane[2], (long long)p->wav_head_own, p->d_wav_peaks + 1);
@@ -2322,20 +2336,85 @@ int upx_comm_create(upx_comm** out, upx_plan* plan, int rank, int n_ranks, const
     c->plan = plan;
     c->rank = rank;
     c->n_ranks = n_ranks;
+    if (const char* e = std::getenv("UPX_COMM_TIMEOUT")) c->timeout_s = std::atof(e);
+    else if (const char* e2 = std::getenv("UPX_RDZV_TIMEOUT")) c->timeout_s = std::atof(e2);
+    if (!(c->timeout_s > 0.0)) c->timeout_s = 600.0;
+    // (blocking: every rank must arrive - the callers vote over their process group BEFORE this call and keep a watchdog
+    // on it, sharding.RcclSeam)
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
     if (r != ncclSuccess) {
         delete c;
         return fail(UPX_ERR_RCCL, "ncclCommInitRank(rank %d of %d): %s", rank, n_ranks, g_rccl.GetErrorString(r));
     }
+    if (hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) c->ev_done = nullptr;
     *out = c;
     return UPX_OK;
+}
+
+// The one way out of a collective whose peer never arrives: ncclCommAbort makes the communicator's kernels leave and frees
+// it.  The planes behind it hold garbage; the caller reports failure and the process ends (a fresh process is the only
+// restart).  Idempotent.
+int upx_comm_abort(upx_comm* c) {
+    if (!c) return fail(UPX_ERR_INVALID, "upx_comm_abort: NULL");
+    if (c->aborted || !c->comm) return UPX_OK;
+    c->aborted = true;
+    c->pending = false;
+    ncclComm_t comm = c->comm;
+    c->comm = nullptr;
+    if (!g_rccl.CommAbort) return fail(UPX_ERR_RCCL, "this librccl has no ncclCommAbort");
+    NCCL_TRY(g_rccl.CommAbort(comm));
+    return UPX_OK;
+}
+
+// Waits until the last queued seam exchange has run on the plan's stream.  timeout_s < 0: the communicator's default
+// (UPX_COMM_TIMEOUT / UPX_RDZV_TIMEOUT / 600 s).  If the time runs out - a peer that never entered the all-reduce - or
+// RCCL reports an asynchronous error, the communicator is ABORTED and an error returned, instead of a
+// hipStreamSynchronize that never comes back.
+int upx_comm_wait(upx_comm* c, double timeout_s) {
+    if (!c) return fail(UPX_ERR_INVALID, "upx_comm_wait: NULL");
+    if (c->aborted) return fail(UPX_ERR_RCCL, "the communicator has been aborted");
+    if (!c->pending) return UPX_OK;
+    HIP_TRY(hipSetDevice(c->plan->device));
+    if (!c->ev_done) {   // (no event: plain wait)
+        HIP_TRY(hipStreamSynchronize(c->plan->stream));
+        c->pending = false;
+        return UPX_OK;
+    }
+    const double limit = timeout_s >= 0.0 ? timeout_s : c->timeout_s;
+    const double t0 = wall_ms();
+    long long spins = 0;
+    for (;;) {
+        const hipError_t q = hipEventQuery(c->ev_done);
+        if (q == hipSuccess) {
+            c->pending = false;
+            return UPX_OK;
+        }
+        if (q != hipErrorNotReady) return fail(UPX_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+        const double waited = (wall_ms() - t0) * 1e-3;
+        if ((++spins & 255) == 0 && g_rccl.CommGetAsyncError && c->comm) {
+            ncclResult_t async = ncclSuccess;
+            if (g_rccl.CommGetAsyncError(c->comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+                const char* what = g_rccl.GetErrorString(async);
+                (void)upx_comm_abort(c);
+                return fail(UPX_ERR_RCCL, "rank %d: the seam all-reduce failed (%s); communicator aborted", c->rank, what);
+            }
+        }
+        if (waited > limit) {
+            (void)upx_comm_abort(c);
+            return fail(UPX_ERR_RCCL, "rank %d: the seam all-reduce did not finish within %.1f s (a peer never arrived); "
+                                      "communicator aborted", c->rank, limit);
+        }
+        if (waited < 2e-3) continue;                       // a healthy exchange takes tens of microseconds: spin first
+        std::this_thread::sleep_for(std::chrono::microseconds(waited < 0.1 ? 50 : 1000));
+    }
 }
 
 void upx_comm_destroy(upx_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->plan->device);
     if (c->d_seam) (void)hipFree(c->d_seam);
-    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->comm && !c->aborted && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
 }
 
@@ -2346,6 +2425,7 @@ namespace {
 int seam_exchange_impl(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t own_len, int64_t spill, int n_rows,
                        int my_row, bool pack, int add_row, int64_t add_len) {
     upx_plan* p = c->plan;
+    if (c->aborted || !c->comm) return fail(UPX_ERR_RCCL, "the communicator has been aborted");
     HIP_TRY(hipSetDevice(p->device));
     const long long row = 3 * (long long)spill, total = row * n_rows;
     if (c->seam_floats < total) {
@@ -2365,9 +2445,27 @@ int seam_exchange_impl(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t 
                            prev + spill, prev + 2 * spill, (long long)add_len);
     }
     HIP_TRY(hipGetLastError());
+    if (c->ev_done) HIP_TRY(hipEventRecord(c->ev_done, p->stream));
+    c->pending = true;
     return UPX_OK;
 }
 }   // namespace
+
+// The seam buffer of `n_ranks` rows for this spill, up front (upx_comm_seam_exchange otherwise allocates it - a
+// synchronising call - inside the first exchange).
+int upx_comm_reserve(upx_comm* c, int64_t spill) {
+    if (!c || spill < 0) return fail(UPX_ERR_INVALID, "upx_comm_reserve: bad argument");
+    const long long total = 3LL * spill * c->n_ranks;
+    if (c->seam_floats >= total) return UPX_OK;
+    HIP_TRY(hipSetDevice(c->plan->device));
+    HIP_TRY(hipStreamSynchronize(c->plan->stream));
+    if (c->d_seam) HIP_TRY(hipFree(c->d_seam));
+    c->d_seam = nullptr;
+    c->seam_floats = 0;
+    HIP_TRY(hipMalloc(&c->d_seam, (size_t)total * sizeof(float)));
+    c->seam_floats = total;
+    return UPX_OK;
+}
 
 int64_t upx_comm_seam_add_len(int rank, int n_ranks, int64_t own_len, int64_t spill) {
     if (rank <= 0 || rank >= n_ranks || own_len <= 0 || spill <= 0) return 0;

@@ -444,19 +444,30 @@ class MultiBandExtractorAccu:
             plan.close()
         self._streaming = False
 
-    # the reference's accumulator attributes (:269-271): host arrays until streaming starts, then read from the device
+    # The reference's accumulator attributes (:269-271): host arrays until streaming starts, then the overlap-add ring lives
+    # on the device.  Reading an attribute then returns a COPY read back from the device (one synchronisation + 3 N floats
+    # down), marked read-only: the reference's in-place idiom `ext.accumC[:] = 0` (:402-424) would otherwise write into a
+    # temporary and be silently lost - here it raises.  Whole-attribute assignment (`ext.accumC = x`, `ext.accumC += x`)
+    # goes through the setter and reaches the device.
     def _accum_get(self, k: int) -> np.ndarray:
-        if self._streaming and self._plan is not None:
-            return self._plan.stream_state(clear=False)[k]
+        plan = self._plan
+        if self._streaming and plan is not None:
+            with plan.lock:
+                arr = plan.stream_state(clear=False)[k]
+            arr.flags.writeable = False
+            return arr
         return self._accum[k]
 
     def _accum_set(self, k: int, value) -> None:
-        cur = [self._accum_get(i) for i in range(3)]
-        cur[k] = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float32), (self.block_size,)))
-        if self._streaming and self._plan is not None:
-            self._plan.stream_set_state(*cur)
+        new = np.array(np.broadcast_to(np.asarray(value, dtype=np.float32), (self.block_size,)), dtype=np.float32, copy=True)
+        plan = self._plan
+        if self._streaming and plan is not None:
+            with plan.lock:
+                cur = list(plan.stream_state(clear=False))
+                cur[k] = new
+                plan.stream_set_state(*cur)
         else:
-            self._accum = [np.array(c, dtype=np.float32, copy=True) for c in cur]
+            self._accum[k] = new
 
     accumC = property(lambda self: self._accum_get(0), lambda self, v: self._accum_set(0, v))
     accumL = property(lambda self: self._accum_get(1), lambda self, v: self._accum_set(1, v))
@@ -493,14 +504,18 @@ class MultiBandExtractorAccu:
         plan = self._device_plan()
         l = np.ascontiguousarray(blkL, dtype=np.float32)
         r = np.ascontiguousarray(blkR, dtype=np.float32)
+        if l.ndim != 1 or r.ndim != 1 or len(l) > n or len(r) > n:
+            # the reference fails as well (forward_stft: block * window cannot broadcast, :366-367); a wrong chunker in the
+            # caller must not come back as wrong audio
+            raise ValueError(f"operands could not be broadcast together with shapes ({len(l)},) ({n},): a block is at most "
+                             f"block_size = {n} samples")
         outs = [np.empty(hop, dtype=np.float32) for _ in range(3)]
         with plan.lock:
             if not self._streaming:
                 if any(a.any() for a in self._accum):
                     plan.stream_set_state(*self._accum)       # accumulators a caller filled before the first block
                 self._streaming = True
-            _lib.check(plan._lib.upx_stream_chunk(plan.handle, _f32p(l), min(len(l), n), _f32p(r), min(len(r), n),
-                                                  *(_f32p(o) for o in outs)))
+            _lib.check(plan._lib.upx_stream_chunk(plan.handle, _f32p(l), len(l), _f32p(r), len(r), *(_f32p(o) for o in outs)))
         return tuple(outs)
 
     def flush_final(self) -> tuple:

@@ -63,6 +63,22 @@ class _Solo:
             raise RuntimeError(message)
 
 
+def _vote(group, exc: Optional[BaseException]) -> None:
+    """
+    Collective: every rank says whether it got this far (`exc` = what stopped it, or None).  If any rank failed, EVERY rank
+    raises - the one that failed its own exception, the others a RendezvousError that names it - so nobody walks into the
+    next collective (RCCL's blocking init, the seam all-reduce inside wav_shard_seal) to wait for a peer that will not come.
+    """
+    try:
+        group.all_ok(exc is None, "" if exc is None else f"{type(exc).__name__}: {exc}")
+    except Exception:
+        if exc is not None:
+            raise exc from None
+        raise
+    if exc is not None:      # (a group whose all_ok does not raise)
+        raise exc
+
+
 def _global_scale(peak_in: float, peak_out: float):
     """main.py:53-55 and :85-90 on the maxima over all ranks -> (peak_in, overall_peak, scale_factor float64)."""
     if peak_in <= 0.0:                       # (a NaN peak stays NaN, as in main.py)
@@ -73,12 +89,19 @@ def _global_scale(peak_in: float, peak_out: float):
 
 def run_rank(in_path: str, out_dir: str, export_mode: str, bands, overlap: float, subtype: str, rank: int, world: int,
              group=None, engine: Optional[Callable] = None, device: int = 0, log=print, host_export: bool = False,
-             times: Optional[dict] = None):
+             times: Optional[dict] = None, plan_factory: Optional[Callable] = None, seam_factory: Optional[Callable] = None):
     """
     One rank's part of the job; returns {key: path} of the files (written by all ranks together).
     `group`: the process group (rendezvous.Rendezvous or anything with allreduce_max / broadcast_bytes / barrier /
     all_ok); None for a single rank.  `engine(local_stereo, shard, geo) -> (center, left, right)` replaces the GPU (the
     CPU tests plug the oracle + their own seam in) and implies the host flow.  `times`: filled with seconds per phase.
+    `plan_factory(bands, device)` / `seam_factory(plan, rank, world, broadcast=, all_ok=)`: stand-ins for DevicePlan and
+    sharding.RcclSeam (the CPU test of the failure containment: a rank that raises between open and seal).
+
+    Failure containment: the ranks vote (`_vote`) after plan creation (before RCCL's blocking init), inside RcclSeam around
+    that init, and between the last feed and wav_shard_seal (which contains the seam all-reduce); a rank that fails in
+    between raises on EVERY rank instead of leaving its peers inside a collective.  What no vote can catch - a peer that
+    dies inside the collective - ends in upx_comm_wait's timeout and ncclCommAbort.  The process then exits non-zero.
     """
     group = group if group is not None else _Solo()
     t_mark = [time.perf_counter()]
@@ -107,10 +130,18 @@ def run_rank(in_path: str, out_dir: str, export_mode: str, bands, overlap: float
     plan = seam = None
     try:
         if engine is None:
-            from .extractor import DevicePlan
-            plan = DevicePlan(bands, device)
+            failure = None
+            try:
+                if plan_factory is None:
+                    from .extractor import DevicePlan
+                    plan_factory = DevicePlan
+                plan = plan_factory(bands, device)
+            except Exception as exc:   # noqa: BLE001 - voted on, then raised
+                failure = exc
+            _vote(group, failure)                      # every rank has its plan before anybody enters RCCL's blocking init
             if world > 1:
-                seam = sharding.RcclSeam(plan, rank, world, broadcast=group.broadcast_bytes)
+                seam = (seam_factory or sharding.RcclSeam)(plan, rank, world, broadcast=group.broadcast_bytes,
+                                                           all_ok=group.all_ok)
         spill = geo.spill if world > 1 else 0
         pieces = None
         if on_device:
@@ -119,18 +150,24 @@ def run_rank(in_path: str, out_dir: str, export_mode: str, bands, overlap: float
             # nothing is decoded on the host
             block = meta["bits"] // 8 * channels
             t_out = shard.own_len + (0 if shard.last else spill)
-            raw = plan.host_empty(shard.t_in * block)
-            plan.wav_shard_open(kind, channels, shard.t_in, shard.own_len, t_out, spill, seam)
-            with ThreadPoolExecutor(max_workers=IO_THREADS) as pool:
-                futs = [pool.submit(wav.read_raw_range, in_path, shard.start + a, min(PIECE_FRAMES, shard.t_in - a), meta,
-                                    raw[a * block:(a + min(PIECE_FRAMES, shard.t_in - a)) * block])
-                        for a in range(0, shard.t_in, PIECE_FRAMES)]
-                for a, fut in zip(range(0, shard.t_in, PIECE_FRAMES), futs):
-                    n = min(PIECE_FRAMES, shard.t_in - a)
-                    if fut.result().size != n * block:
-                        raise ValueError(f"{in_path}: file ends inside the sample data")
-                    plan.wav_shard_feed(raw[a * block:(a + n) * block], n)          # in file order
+            failure = None
+            try:
+                raw = plan.host_empty(shard.t_in * block)
+                plan.wav_shard_open(kind, channels, shard.t_in, shard.own_len, t_out, spill, seam)
+                with ThreadPoolExecutor(max_workers=IO_THREADS) as pool:
+                    futs = [pool.submit(wav.read_raw_range, in_path, shard.start + a, min(PIECE_FRAMES, shard.t_in - a), meta,
+                                        raw[a * block:(a + min(PIECE_FRAMES, shard.t_in - a)) * block])
+                            for a in range(0, shard.t_in, PIECE_FRAMES)]
+                    for a, fut in zip(range(0, shard.t_in, PIECE_FRAMES), futs):
+                        n = min(PIECE_FRAMES, shard.t_in - a)
+                        if fut.result().size != n * block:
+                            raise ValueError(f"{in_path}: file ends inside the sample data")
+                        plan.wav_shard_feed(raw[a * block:(a + n) * block], n)          # in file order
+            except Exception as exc:   # noqa: BLE001 - an I/O error in a reader thread, UPX_ERR_NOMEM ...: voted on, then raised
+                failure = exc
             lap("read_s")
+            # seal contains the seam all-reduce (upx_comm_seam_exchange): nobody enters it unless every rank has fed its shard
+            _vote(group, failure)
             peaks = plan.wav_shard_seal()
             lap("device_begin_s")
             peak_in, overall_peak, scale_factor = _global_scale(*group.allreduce_max(peaks))
@@ -140,12 +177,17 @@ def run_rank(in_path: str, out_dir: str, export_mode: str, bands, overlap: float
             pieces = (n_pieces, per)
             lap("device_finish_s")
         else:
-            local = wav.read_range(in_path, shard.start, shard.t_in, meta)     # own range + right halo, nothing else
-            if local.ndim == 1:
-                local = np.column_stack([local, local])                        # main.py:47-48
-            own = local[:shard.own_len]
-            stereo = np.ascontiguousarray(local[:, :2])                        # main.py:49-50: wave[:,0], wave[:,1]
+            failure = None
+            try:
+                local = wav.read_range(in_path, shard.start, shard.t_in, meta)     # own range + right halo, nothing else
+                if local.ndim == 1:
+                    local = np.column_stack([local, local])                        # main.py:47-48
+                own = local[:shard.own_len]
+                stereo = np.ascontiguousarray(local[:, :2])                        # main.py:49-50: wave[:,0], wave[:,1]
+            except Exception as exc:   # noqa: BLE001
+                failure = exc
             lap("read_s")
+            _vote(group, failure)          # the engines below end in the seam all-reduce
             if engine is None:
                 c, l, r = sharding.process_local_shard(plan, stereo, shard, geo, world, seam)
             else:

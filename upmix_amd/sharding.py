@@ -157,6 +157,7 @@ def process_local_shard(plan, local: np.ndarray, shard: Shard, geo: ShardGeometr
         plan.process_device(d_in, shard.t_in, shard.own_len, planes[0], planes[1], planes[2], shard.t_out)
         if world > 1:
             seam.exchange(planes, shard.own_len, spill)
+            seam.wait()          # bounded: a peer that never entered the all-reduce must not hold the download below for ever
         outs = [np.empty(shard.own_len, dtype=np.float32) for _ in range(3)]
         for o, d in zip(outs, planes):
             plan.d2h(o, d)
@@ -180,27 +181,112 @@ def process_rank(plan, stereo: np.ndarray, rank: int, world: int, seam: Optional
     return shard, process_local_shard(plan, local, shard, geo, world, seam)
 
 
-class RcclSeam:
-    """One RCCL communicator per process/GPU for the seam all-reduce (upx_comm_* in the C ABI).
-    `broadcast(payload_or_None) -> bytes` hands rank 0's 128-byte RCCL id to every rank (rendezvous.Rendezvous
-    .broadcast_bytes in the product entries)."""
+class _Watchdog:
+    """
+    Ends the process if the body does not return in time.  For the one blocking collective call that has no error path of
+    its own (ncclCommInitRank: a rank whose peer never arrives waits inside it for ever; ctypes has released the GIL, so
+    the timer thread runs).  The main thread is inside a C call that will never return, so no exception can reach it: the
+    watchdog writes the reason to stderr and terminates the process with SIGTERM's default action (status 143; launchers
+    report it as a failed rank) - a fresh process is the only restart.
+    """
 
-    def __init__(self, plan, rank: int, world: int, broadcast: Callable[[Optional[bytes]], bytes]):
+    def __init__(self, seconds: float, what: str):
+        self.seconds, self.what, self._timer = float(seconds), what, None
+
+    def _fire(self):
+        import os
+        import signal
+        import sys
+        print(f"[upmix_amd] {self.what} did not return within {self.seconds:g} s: a peer never arrived; terminating",
+              file=sys.stderr, flush=True)
+        os.kill(os.getpid(), signal.SIGTERM)
+
+    def __enter__(self):
+        import threading
+        if self.seconds > 0:
+            self._timer = threading.Timer(self.seconds, self._fire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
+def comm_timeout(env=None) -> float:
+    """Seconds a rank waits for its peers in a collective before it gives up: UPX_COMM_TIMEOUT, else UPX_RDZV_TIMEOUT, else 600."""
+    import os
+    env = os.environ if env is None else env
+    for key in ("UPX_COMM_TIMEOUT", "UPX_RDZV_TIMEOUT"):
+        try:
+            v = float(env.get(key, ""))
+            if v > 0:
+                return v
+        except ValueError:
+            pass
+    return 600.0
+
+
+class RcclSeam:
+    """
+    One RCCL communicator per process/GPU for the seam all-reduce (upx_comm_* in the C ABI).
+    `broadcast(payload_or_None) -> bytes` hands rank 0's 128-byte RCCL id to every rank (rendezvous.Rendezvous
+    .broadcast_bytes in the product entries).
+
+    Failure containment (the reference fails with plain exceptions, main.py:40-41; a collective has no error path):
+    `all_ok(ok, message)` - rendezvous.Rendezvous.all_ok - is voted BEFORE the blocking ncclCommInitRank (rank 0 has an
+    id, every rank got this far) and AFTER it (every rank has a communicator; a rank that has one while a peer failed
+    aborts it); a watchdog ends the process if the init itself never returns; `wait()` bounds the wait for an
+    exchange and aborts the communicator when a peer never entered it (upx_comm_wait).
+    """
+
+    def __init__(self, plan, rank: int, world: int, broadcast: Callable[[Optional[bytes]], bytes],
+                 all_ok: Optional[Callable[[bool, str], None]] = None, timeout: Optional[float] = None):
         self._lib = _lib.load()
         self.plan = plan
-        uid = None
+        self.handle = None
+        self.timeout = comm_timeout() if timeout is None else float(timeout)
+        vote = all_ok if all_ok is not None else (lambda ok=True, message="": None)
+        uid, err = None, ""
         if rank == 0:
-            buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
-            _lib.check(self._lib.upx_comm_unique_id(buf))
-            uid = buf.raw
+            try:
+                buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+                _lib.check(self._lib.upx_comm_unique_id(buf))
+                uid = buf.raw
+            except Exception as exc:   # noqa: BLE001 - reported to every rank by the vote
+                err = f"{type(exc).__name__}: {exc}"
+        vote(not err, err)
+        if err:
+            raise _lib.UpmixHipError(err)
         uid = broadcast(uid)
         handle = C.c_void_p()
-        _lib.check(self._lib.upx_comm_create(C.byref(handle), plan.handle, rank, world, uid))
-        self.handle = handle
+        with _Watchdog(self.timeout, f"rank {rank}: ncclCommInitRank"):
+            rc = self._lib.upx_comm_create(C.byref(handle), plan.handle, rank, world, uid)
+        err = "" if rc == _lib.UPX_OK else self._lib.upx_last_error().decode("utf-8", "replace")
+        if rc == _lib.UPX_OK:
+            self.handle = handle
+        try:
+            vote(not err, err)
+        except Exception:
+            self.abort()
+            raise
+        if err:
+            raise _lib.UpmixHipError(err)
 
     def exchange(self, d_planes: Sequence[int], own_len: int, spill: int) -> None:
         _lib.check(self._lib.upx_comm_seam_exchange(self.handle, *(C.c_void_p(p) for p in d_planes),
                                                     int(own_len), int(spill)))
+
+    def wait(self, timeout: Optional[float] = None) -> None:
+        """Until the last queued exchange has run; aborts the communicator and raises when `timeout` (default: the
+        communicator's) runs out or RCCL reports an error - instead of a stream synchronisation that never returns."""
+        _lib.check(self._lib.upx_comm_wait(self.handle, -1.0 if timeout is None else float(timeout)))
+
+    def abort(self) -> None:
+        if self.handle:
+            self._lib.upx_comm_abort(self.handle)
 
     def selftest(self, d_planes: Sequence[int], own_len: int, spill: int, n_rows: int, my_row: int) -> None:
         """pack -> ncclAllReduce -> add with an n_rows seam on this communicator (see upx_comm_seam_selftest)."""
