@@ -156,9 +156,10 @@ def cpu_baseline(workload, target_seconds=15.0):
     whole = sample_seconds >= seconds
     out = {
         "value": round(total / dt / 1e6, 4), "unit": "Msamples/s",
-        "cores": threads, "threads_used": threads,
-        "cores_note": "threads that ran the frame loops: one task per band in the reference's ThreadPoolExecutor(), i.e. "
-                      "the band count (the GIL serialises most of it); the host's CPU count is host_cpus",
+        "cores": host["usable_cpus"], "threads_used": threads,
+        "cores_note": "cores = the CPUs of the box this process may run on (north_star: the core count of the host the CPU "
+                      "line was timed on); threads_used = one task per band in the reference's ThreadPoolExecutor() "
+                      "(center_extraction.py:499-501), most of whose work the GIL serialises",
         "kind": "port",
         "bands_serial_value": round(serial, 4),
         "sample": (f"the WHOLE workload ({sample_seconds:g} s of audio, seed {seed})" if whole else
@@ -466,6 +467,10 @@ def main():
                 comm.exchange(d_out, own, spill)
         calls_per_step = 1
 
+    # the first call of a shape otherwise allocates its seam / scratch buffers and uploads its stream tables on the way
+    # (synchronising calls): prepared up front, so that what the first steps cost beyond a steady step is the card's clocks
+    plan.reserve(*((nominal, nominal, nominal) if batch else (t_in, own, t_out)))
+
     def barrier():
         if hasattr(comm, "wait"):
             comm.wait()      # bounded: a peer that never entered the all-reduce aborts the communicator instead of hanging the sync
@@ -519,6 +524,30 @@ def main():
     if calls_per_step > 1 and len(step_ms) >= calls_per_step:
         step_ms = step_ms[len(step_ms) % calls_per_step:].reshape(-1, calls_per_step).sum(axis=1)
     median_ms = float(np.median(step_ms[-10:])) if len(step_ms) else None
+
+    # How much of a cold call is the card and how much is software: the same five steps again after 2 s of idling, with
+    # every buffer, table and code object touched - what is left of the difference to a steady step is the clock ramp alone.
+    idle_ms = None
+    if args.preheat_ms > 0 and world == 1:
+        time.sleep(2.0)
+        t_idle = time.perf_counter()
+        for _ in range(5):
+            step()
+        plan.sync()
+        idle_ms = (time.perf_counter() - t_idle) * 1e3 / 5
+    # what a pass with these kernels' lane pattern (4 bytes per lane, grid-stride) reaches on this card, measured in this
+    # run: x *= 1.0f over one output plane (upx_scale: one load and one store per sample, values unchanged)
+    stream_gbps = None
+    if world == 1 and not batch:
+        n_probe = int(own)
+        for _ in range(3):
+            plan.scale(d_out[0], n_probe, 1.0)
+        plan.sync()
+        t_p = time.perf_counter()
+        for _ in range(20):
+            plan.scale(d_out[0], n_probe, 1.0)
+        plan.sync()
+        stream_gbps = 8.0 * n_probe * 20 / (time.perf_counter() - t_p) / 1e9
 
     if rank == 0:
         total_samples = samples_per_step_rank * world if not batch else nominal * TRACKS_PER_GPU * world
@@ -588,6 +617,11 @@ def main():
             "warmup": args.warmup,
             "preheat": {"untimed_steps": preheat_steps, "ms": args.preheat_ms,
                         "first_5_steps_ms_per_step": None if cold_ms is None else round(cold_ms, 4),
+                        "five_steps_after_2s_idle_ms_per_step": None if idle_ms is None else round(idle_ms, 4),
+                        "software_share_of_a_cold_step_ms": None if idle_ms is None or cold_ms is None else round(cold_ms - idle_ms, 4),
+                        "cold_note": "first_5 = the first calls of this process (after upx_plan_reserve: buffers and stream "
+                                     "tables prepared); after_2s_idle = the same steps on an idle card with everything touched "
+                                     "= the clock ramp alone; their difference is what software still adds to a cold call",
                         "why": "an idle card reaches its running clocks after ~20 steps; run before the warm-up steps, "
                                "never inside the timed region (scripts/clock_ramp_check.py, DESIGN.md 5)"},
             "kernel_timing": {"steps_with_events": timed_steps, "stride": TIMING_STRIDE,
@@ -628,10 +662,12 @@ def main():
                 "bands_in_launch": dom["bands"],
                 "avg_launch_ms": dom["ms"],
                 "traffic_ratio": dom["traffic_ratio"],
-                # what a streaming kernel with these kernels' lane pattern reaches on this part (scripts/microbench/atomic_rmw.hip,
-                # store 5.3 TB/s, load + add + store 5.5 TB/s): `peak` stays the guide's 8 TB/s
-                "measured_streaming_GBps": 5500.0,
-                "traffic_frac_of_measured_streaming": None if not traffic else round(traffic / (dom["ms"] * 1e-3) / 1e9 / 5500.0, 4),
+                # what a pass with these kernels' lane pattern (4 bytes per lane) reaches on THIS card in THIS run (x *= 1.0f over
+                # one output plane: load + store); the guide's 16-byte-per-lane copy reaches 6290 GB/s; `peak` stays its 8 TB/s
+                "lane_pattern_streaming_GBps": None if stream_gbps is None else round(stream_gbps, 1),
+                "guide_float4_copy_GBps": 6290.0,
+                "traffic_frac_of_lane_pattern_streaming": None if not traffic or not stream_gbps else
+                round(traffic / (dom["ms"] * 1e-3) / 1e9 / stream_gbps, 4),
                 "limiter": "not HBM bandwidth: VALU issue + LDS exchanges at 2-4 waves per SIMD, and for the fused kernels the "
                            "in-order vector L1 (DESIGN.md 5, 8); `valu.executed` is the ceiling that binds",
             },

@@ -40,27 +40,46 @@ def main():
                            xover_mode="raised_cosine", max_block_size=args.max_stft, verbose=False)
     t_chain = time.perf_counter() - t0
     L, R = wave[:, 0], wave[:, 1]                       # main.py:49-50
+    # what the first call spends before any sample moves: the HIP runtime comes up (first runtime call of the process), the
+    # library's code objects load, the plan's tables and device buffers are made - timed apart by creating the plan the entry
+    # is about to look up in its cache (extractor._checked_out_plan)
+    from upmix_amd import extractor
     t0 = time.perf_counter()
-    c, l, r = ce.extract_center_left_right_multi_band_in_memory(L, R, args.sr, bands)
+    with extractor._checked_out_plan(bands, 0):
+        pass
+    t_plan = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res = ce.extract_center_left_right_multi_band_in_memory(L, R, args.sr, bands)
     t_first = time.perf_counter() - t0
+    keep = [a.copy() for a in res]
+    pageable = all(a.base is None for a in res)
+    del res                                              # a caller that is done with a result lets it go: its blocks are reused
     t0 = time.perf_counter()
-    c2, l2, r2 = ce.extract_center_left_right_multi_band_in_memory(L, R, args.sr, bands)
+    res = ce.extract_center_left_right_multi_band_in_memory(L, R, args.sr, bands)
     t_second = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    c3, l3, r3 = ce.extract_center_left_right_multi_band_in_memory(L, R, args.sr, bands)
-    t_third = time.perf_counter() - t0
+    same = all(np.array_equal(a, b) for a, b in zip(res, keep))
+    del res
+    steady = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = ce.extract_center_left_right_multi_band_in_memory(L, R, args.sr, bands)
+        steady.append(time.perf_counter() - t0)
+        del res
     # the host cast + interleave this entry used to make before the first byte moved (round 4: extractor.py:521)
     t0 = time.perf_counter()
     np.stack([np.asarray(L, dtype=np.float32), np.asarray(R, dtype=np.float32)], axis=1)
     t_stack = time.perf_counter() - t0
     print(json.dumps({
         "samples": total, "import_ms": round(t_import * 1e3, 1), "chain_bands_ms": round(t_chain * 1e3, 1),
-        "first_call_ms": round(t_first * 1e3, 1), "second_call_ms": round(t_second * 1e3, 1),
-        "third_call_ms": round(t_third * 1e3, 1),
+        "runtime_and_plan_ms": round(t_plan * 1e3, 1),
+        "first_call_ms": round(t_first * 1e3, 1), "first_call_results_pageable": bool(pageable),
+        "second_call_ms": round(t_second * 1e3, 1), "steady_call_ms": round(min(steady) * 1e3, 1),
+        "one_shot_total_ms": round((t_import + t_chain + t_plan + t_first) * 1e3, 1),
         "host_cast_and_interleave_it_replaces_ms": round(t_stack * 1e3, 1),
-        "identical_results": bool(np.array_equal(c, c2) and np.array_equal(l, l3) and np.array_equal(r, r2)),
-        "note": "first call = plan creation (tables, device buffers) + the call into pageable result arrays; second call pins "
-                "its result blocks (pooled page-locked memory from then on); third = steady"}))
+        "identical_results": bool(same),
+        "note": "runtime_and_plan = HIP runtime start + code objects + plan tables / device buffers (once per process and band "
+                "list); first call -> pageable result arrays (a one-shot process pays no pinning); second call pins its result "
+                "blocks; steady = pooled page-locked results, each result dropped before the next call"}))
 
 
 if __name__ == "__main__":

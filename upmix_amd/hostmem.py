@@ -160,7 +160,10 @@ class PinnedPool:
             self._release_idle(plan_handle)
             self.plans_live = False     # (DevicePlan.close calls this for the process' last plan)
             self._asked.clear()
-            if self._held > 0 and self._sweeper is None and not self.closed:
+            # (never at interpreter shutdown - a plan closed by its finaliser: a thread started then cannot run and
+            # Thread.start() would wait for it for ever)
+            if (self._held > 0 and self._sweeper is None and not self.closed and not sys.is_finalizing()
+                    and threading.main_thread().is_alive()):
                 self._sweeper = threading.Thread(target=self._sweep, name="upx-pinned-pool-sweeper", daemon=True)
                 self._sweeper.start()
 
