@@ -535,6 +535,16 @@ def main():
             step()
         plan.sync()
         idle_ms = (time.perf_counter() - t_idle) * 1e3 / 5
+    # host work of one process_device call (launch geometry, stream tables: std::vector work per call): the same code path
+    # without the launches (upx_plan_reserve's dry run + one synchronisation of the idle stream)
+    prep_us = None
+    if world == 1:
+        shape = (nominal, nominal, nominal) if batch else (t_in, own, t_out)
+        plan.sync()
+        t_h = time.perf_counter()
+        for _ in range(50):
+            plan.reserve(*shape)
+        prep_us = (time.perf_counter() - t_h) / 50 * 1e6
     # what a pass with these kernels' lane pattern (4 bytes per lane, grid-stride) reaches on this card, measured in this
     # run: x *= 1.0f over one output plane (upx_scale: one load and one store per sample, values unchanged)
     stream_gbps = None
@@ -647,6 +657,7 @@ def main():
                     if os.environ.get("UPX_BENCH_REHEARSAL") != "1" else f"REHEARSAL x{world} (host seam, shared device) - not a result"),
             },
             "median_kernel_ms_per_step": None if median_ms is None else round(median_ms, 4),
+            "host_prep_us_per_call": None if prep_us is None else round(prep_us, 1),
             "roofline": {
                 "bound": "hbm (prescribed)",
                 "binding_ceiling": "fp32 vector issue (valu.executed, launches[].valu_frac) - not HBM bandwidth",

@@ -52,7 +52,8 @@ def main():
     res = ce.extract_center_left_right_multi_band_in_memory(L, R, args.sr, bands)
     t_first = time.perf_counter() - t0
     keep = [a.copy() for a in res]
-    pageable = all(a.base is None for a in res)
+    from upmix_amd import hostmem
+    pageable = not any(hostmem.is_pinned(a) for a in res)
     del res                                              # a caller that is done with a result lets it go: its blocks are reused
     t0 = time.perf_counter()
     res = ce.extract_center_left_right_multi_band_in_memory(L, R, args.sr, bands)

@@ -387,9 +387,9 @@ def test_results_live_in_pooled_page_locked_memory(ux, orc, monkeypatch):
     hostmem.POOL._asked.clear()
     held0 = hostmem.POOL._held
     first = plan.process(x)
-    assert all(o.base is None for o in first) and hostmem.POOL._held == held0
+    assert not any(hostmem.is_pinned(o) for o in first) and hostmem.POOL._held == held0
     a = plan.process(x)
-    assert all(o.base is not None for o in a) and all(np.array_equal(o, q) for o, q in zip(a, first))
+    assert all(hostmem.is_pinned(o) for o in a) and all(np.array_equal(o, q) for o, q in zip(a, first))
     del first
     keep = [o.copy() for o in a]
     b = plan.process(y)                                # `a` is still held: `b` must not land on its blocks
@@ -466,6 +466,37 @@ def test_drop_in_entry_takes_the_callers_arrays_as_they_are(ux, orc):
         plan.process_lr(wave[:, 0], wave[:-1, 1])
     assert all(o.shape == (0,) for o in plan.process_lr(np.zeros(0), np.zeros(0)))
     plan.close()
+
+
+def test_plan_reserve_prepares_a_call_shape(ux, orc):
+    """upx_plan_reserve: everything the first process_device call of a shape allocates / uploads / loads, up front - no
+    signal buffer is touched, the result is bit for bit the one without it, any shape may be reserved (and re-reserved)."""
+    x = orc.synthetic_stereo(400000, 12)
+    bands = gpu_chain(ux, [0, 120, 480, 4000], 48000, 8192, 32)
+    outs = []
+    for reserve in (False, True):
+        plan = ux.DevicePlan(bands)
+        total = x.shape[0]
+        if reserve:
+            plan.reserve(total, total, total)
+            plan.reserve(0, 0, 0)
+            plan.reserve(12345, 12345, 12345)          # another shape in between: the tables follow the last one asked for
+            plan.reserve(total, total, total)
+        d_in = plan.alloc(total * 8)
+        d = [plan.alloc(total * 4) for _ in range(3)]
+        plan.h2d(d_in, x)
+        plan.process_device(d_in, total, total, d[0], d[1], d[2], total)
+        got = [np.empty(total, np.float32) for _ in range(3)]
+        for g, p in zip(got, d):
+            plan.d2h(g, p)
+        outs.append(got)
+        for p in d + [d_in]:
+            plan.free(p)
+        plan.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    with pytest.raises(ValueError):
+        ux.DevicePlan(bands).reserve(-1, 0, 0)
 
 
 def test_dual_stream_experiment_kernels_agree(ux, orc, monkeypatch):

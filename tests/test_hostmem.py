@@ -150,10 +150,10 @@ def test_lazy_pinning_first_call_gets_pageable_arrays(monkeypatch):
     pool, fake = make_pool(monkeypatch, 64 << 20)
     t1 = pool.new_call()
     first = [pool.take(1000, None, lazy=t1) for _ in range(3)]           # one call, three planes of one capacity
-    assert fake.allocs == 0 and all(a.base is None and a.shape == (1000,) for a in first)
+    assert fake.allocs == 0 and all(not hostmem.is_pinned(a) and a.shape == (1000,) for a in first)
     t2 = pool.new_call()
     second = [pool.take(1000, None, lazy=t2) for _ in range(3)]
-    assert fake.allocs == 3 and all(a.base is not None for a in second)
+    assert fake.allocs == 3 and all(hostmem.is_pinned(a) and hostmem.is_pinned(a[5:9].view(np.int16)) for a in second)
     other = pool.take(5 * hostmem._GRANULE, None, lazy=t2)               # another capacity: its own first call
     assert other.base is None and fake.allocs == 3
     del second

@@ -368,6 +368,7 @@ struct upx_plan {
     std::vector<BandState> bands;
     std::map<int, upx::cf*> tw;   // log2n -> device twiddles
     bool timing = false;
+    bool warmed = false;            // upx_plan_reserve has run its tiny warm-up call through every kernel
     bool dry_run = false;           // upx_plan_reserve: upx_process_device prepares (geometry, tables, buffers) and launches nothing
     bool timed_once = false;
     long long timed_calls = 0;      // timed upx_process_device calls since timing was enabled
@@ -1395,6 +1396,26 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
 int upx_plan_reserve(upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out) {
     if (!p || t_in < 0 || own_len < 0 || t_out < 0) return fail(UPX_ERR_INVALID, "upx_plan_reserve: bad argument");
     if (t_out == 0) return UPX_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->warmed) {
+        // One tiny REAL call through every kernel of the plan, on silence: the runtime loads a kernel's code object and sets
+        // the function up on its first launch (tens of microseconds each, ten kernels in a six-band plan) - paid here, not by
+        // the caller's first step.  Then the dry run below prepares the tables and buffers of the shape asked for.
+        int n_max = 0;
+        for (const auto& s : p->bands) n_max = s.n > n_max ? s.n : n_max;
+        const int64_t n = 8LL * n_max;
+        float* tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, (size_t)n * 5 * sizeof(float)));
+        hipError_t e = hipMemsetAsync(tmp, 0, (size_t)n * 2 * sizeof(float), p->stream);
+        const bool timing = p->timing;
+        p->timing = false;
+        int rc = e == hipSuccess ? upx_process_device(p, tmp, n, n, tmp + 2 * n, tmp + 3 * n, tmp + 4 * n, n) : UPX_ERR_HIP;
+        p->timing = timing;
+        (void)hipStreamSynchronize(p->stream);
+        (void)hipFree(tmp);
+        if (rc != UPX_OK) return rc;
+        p->warmed = true;
+    }
     p->dry_run = true;
     const int rc = upx_process_device(p, nullptr, t_in, own_len, nullptr, nullptr, nullptr, t_out);
     p->dry_run = false;

@@ -207,6 +207,14 @@ def _limit_from_env() -> int:
 POOL = PinnedPool(_limit_from_env())
 
 
+def is_pinned(arr) -> bool:
+    """Whether a NumPy array (or any view of one) lives in a block of the page-locked pool."""
+    base = arr
+    while isinstance(base, np.ndarray) and base.base is not None:
+        base = base.base
+    return isinstance(base, _Lease)
+
+
 def empty(nbytes_or_shape, dtype, plan_handle, lazy: int = 0) -> np.ndarray:
     """np.empty(shape, dtype) in pooled page-locked memory (lazy = POOL.new_call() token: see PinnedPool.take)."""
     shape = (nbytes_or_shape,) if np.isscalar(nbytes_or_shape) else tuple(nbytes_or_shape)
