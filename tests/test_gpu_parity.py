@@ -384,7 +384,11 @@ def test_results_live_in_pooled_page_locked_memory(ux, orc, monkeypatch):
     # the FIRST call that asks for a size gets plain NumPy arrays: a one-shot process (the reference's flow, main.py:78-80)
     # must not pay for pinning blocks it never reuses; the second call has proven reuse and pins (hostmem.PinnedPool.take)
     # (earlier tests of this process may have asked for the same size class: forget that, and count pinned bytes from here)
-    hostmem.POOL._asked.clear()
+    # ... and left idle blocks of it behind, which any call may use: release them)
+    gc.collect()
+    with hostmem.POOL._lock:
+        hostmem.POOL._release_idle(plan.handle)
+        hostmem.POOL._asked.clear()
     held0 = hostmem.POOL._held
     first = plan.process(x)
     assert not any(hostmem.is_pinned(o) for o in first) and hostmem.POOL._held == held0

@@ -65,6 +65,36 @@ struct DevExec {
     }
 };
 
+// Stream seams inside the launch (BandArgs::pair_cnt).  Runs after band_program: every stream of the workgroup has written
+// its hops and its tail.  Seams between two streams of ONE workgroup are added right away; for the seam to either
+// neighbour workgroup, the two workgroups count up pair_cnt[w] and the second arriver adds.  Memory: the counter update is
+// an agent-scope acquire-release atomic behind a workgroup barrier (the workgroup's stores are then in the L2 of its XCD; the
+// release writes that L2 back, the acquire invalidates the reader's), which is what makes the other workgroup's tail and
+// head visible across the chip's eight L2s.
+template <class C>
+__device__ __forceinline__ void seam_epilogue(const upx::BandArgs& a, int wg, int n_wg) {
+    constexpr int TAIL = (C::K - 1) * C::HOP;
+    __shared__ int second[2];
+    auto add = [&](int sid) {   // tail of stream sid onto the first blocks of stream sid + 1
+        for (int i = (int)threadIdx.x; i < TAIL; i += (int)blockDim.x)
+            upx::stream_seam_add(a, a.n_streams, TAIL, C::HOP, (long long)sid * TAIL + i);
+    };
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g + 1 < C::G; ++g) add(wg * C::G + g);
+    if (threadIdx.x == 0) {
+        second[0] = wg > 0 ? (__hip_atomic_fetch_add(a.pair_cnt + wg - 1, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) & 1) : 0;
+        second[1] = wg + 1 < n_wg ? (__hip_atomic_fetch_add(a.pair_cnt + wg, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) & 1) : 0;
+    }
+    __syncthreads();
+    const bool s0 = second[0] != 0, s1 = second[1] != 0;
+    if (s0 || s1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (s0) add(wg * C::G - 1);
+        if (s1) add(wg * C::G + C::G - 1);
+    }
+}
+
 // WPE = waves per SIMD the register allocator must leave room for (2 -> 256 VGPRs, 3 -> 168).
 // MERGED = false: the launch carries one band (one gain slot per bin): the flavour single bands get.
 // LV = upx::Live<S0, S1>: single-band flavour specialised for the own-bin slots that carry gain (upx_core.h).
@@ -79,6 +109,7 @@ __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
         upx::band_program_auto<C, Ex, MERGED, LV>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
     else
         upx::band_program<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    if (a.pair_cnt) seam_epilogue<C>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- unfused path: STFT sizes 16384..65536 and arbitrary hops (upx_big.h) ---------------------

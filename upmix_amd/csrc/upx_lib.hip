@@ -386,6 +386,9 @@ struct upx_plan {
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
     int knob_seam_vec = 1;                  // UPX_SEAM_VEC: stream-seam passes with 16-byte accesses where alignment allows (0: scalar passes)
     int knob_first_band = -1;               // UPX_FIRST_BAND: launch this band's group first (-1: list order, the reference's sum order)
+    int knob_seam_inkernel = 2;             // UPX_SEAM_INKERNEL: stream seams of fused launches inside the launch (0 never, 1 always, 2 when the launch does not fill the chip)
+    int* d_pair_cnt = nullptr;              // counters of seam_epilogue, one per neighbouring workgroup pair (only ever grow)
+    int pair_cnt_n = 1 << 16;
     int knob_band_rotate = 0;               // UPX_BAND_ROTATE (experiment): the launch groups start this many groups into the list (another sum association)
     int knob_min_stream_frames = 4;         // UPX_MIN_STREAM_FRAMES: shortest stream of a fused launch that does not fill the chip (>= K, even)
     int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
@@ -624,8 +627,11 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (const char* e = std::getenv("UPX_N_CU"))
         if (std::atoi(e) >= 8) p->n_cu = std::atoi(e);
     if (const char* e = std::getenv("UPX_BAND_ROTATE")) p->knob_band_rotate = std::atoi(e);
+    if (const char* e = std::getenv("UPX_SEAM_INKERNEL")) p->knob_seam_inkernel = std::atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc(&p->d_scalar, sizeof(unsigned int)));
+    HIP_TRY(hipMalloc(&p->d_pair_cnt, (size_t)p->pair_cnt_n * sizeof(int)));
+    HIP_TRY(hipMemset(p->d_pair_cnt, 0, (size_t)p->pair_cnt_n * sizeof(int)));
     p->bands.resize(n_bands);
     std::vector<size_t> band_win_off, band_gain_off;
     // pass 1: geometry, merged groups, pass band
@@ -873,6 +879,7 @@ void upx_plan_destroy(upx_plan* p) {
     }
     for (auto& kv : p->tw) (void)hipFree(kv.second);
     if (p->d_scalar) (void)hipFree(p->d_scalar);
+    if (p->d_pair_cnt) (void)hipFree(p->d_pair_cnt);
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->d_zoom) (void)hipFree(p->d_zoom);
     if (p->d_seam) (void)hipFree(p->d_seam);
@@ -1366,6 +1373,12 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             else if (s.kern->wg == 128 && n_wg > 2LL * p->n_cu) a.prio_split = -p->n_cu;
         }
         a.prio_young = p->knob_prio_young;
+        // stream seams inside the launch (seam_epilogue) or in a launch of their own: UPX_SEAM_INKERNEL = 1 always, 2 (default)
+        // when the launch does not fill the chip - a short signal, where the seam launch is a sixth of the step -, 0 never
+        const bool seam_inside = n_streams > 1 && p->d_pair_cnt && n_wg <= (long long)p->pair_cnt_n &&
+                                 (p->knob_seam_inkernel == 1 || (p->knob_seam_inkernel == 2 && n_wg <= slots));
+        a.pair_cnt = seam_inside ? p->d_pair_cnt : nullptr;
+        a.n_streams = (int)n_streams;
         s.last_wg = (int)n_wg;
         s.last_f = (int)f;
         s.fill_wg = (int)n_wg;
@@ -1373,7 +1386,7 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         s.fill_wg_a = s.fill_slots_a = 0;
         if (timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
         if (!dry) s.kern->launch(a, (int)n_wg, p->stream);
-        if (!dry && n_streams > 1) {
+        if (!dry && n_streams > 1 && !seam_inside) {
             if (seam_vec_ok(p, d_c, d_l, d_r, s.hop) && n_streams <= 65535)
                 hipLaunchKernelGGL(upx_stream_seam_add4_kernel, dim3((unsigned)((tail / 4 + 255) / 256), (unsigned)n_streams), dim3(256), 0,
                                    p->stream, a, (int)n_streams, (int)tail, s.hop);

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(C::WG, 1) void upx_band_dual_kernel(upx::BandArgs a
     using Ex = MultiExec<C::P, V>;
     Ex ex;
     upx::band_program_auto<MultiCfg<C, V>, Ex, false, LV>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+    if (a.pair_cnt) seam_epilogue<MultiCfg<C, V>>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 template <class C, int V, class LV>
