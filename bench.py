@@ -54,6 +54,7 @@ KERNEL_SOURCES = ["upmix_amd/csrc/upx_core.h", "upmix_amd/csrc/upx_zoom.h", "upm
                   "upmix_amd/csrc/upx_kernels.h", "upmix_amd/csrc/upx_lib.hip", "upmix_amd/csrc/upx_reg_big.hip",
                   "upmix_amd/csrc/upx_reg_fused.hip", "upmix_amd/csrc/upx_reg_fused_single.hip",
                   "upmix_amd/csrc/upx_reg_fused_p8.hip", "upmix_amd/csrc/upx_reg_fused_plain.hip",
+                  "upmix_amd/csrc/upx_reg_fused_dual.hip",
                   "upmix_amd/csrc/upx_reg_zoom256.hip", "upmix_amd/csrc/upx_reg_zoom512.hip",
                   "upmix_amd/csrc/upx_reg_zoom1024.hip"]
 

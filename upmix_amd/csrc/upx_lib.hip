@@ -386,7 +386,7 @@ struct upx_plan {
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
     int knob_seam_vec = 1;                  // UPX_SEAM_VEC: stream-seam passes with 16-byte accesses where alignment allows (0: scalar passes)
     int knob_first_band = -1;               // UPX_FIRST_BAND: launch this band's group first (-1: list order, the reference's sum order)
-    int knob_seam_inkernel = 2;             // UPX_SEAM_INKERNEL: stream seams of fused launches inside the launch (0 never, 1 always, 2 when the launch does not fill the chip)
+    int knob_seam_inkernel = 0;             // UPX_SEAM_INKERNEL (experiment, rejected: profiles/r05_seam_inkernel_ab.txt): stream seams of fused launches inside the launch (0 never, 1 always, 2 when the launch does not fill the chip)
     int* d_pair_cnt = nullptr;              // counters of seam_epilogue, one per neighbouring workgroup pair (only ever grow)
     int pair_cnt_n = 1 << 16;
     int knob_band_rotate = 0;               // UPX_BAND_ROTATE (experiment): the launch groups start this many groups into the list (another sum association)
@@ -1373,7 +1373,8 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
             else if (s.kern->wg == 128 && n_wg > 2LL * p->n_cu) a.prio_split = -p->n_cu;
         }
         a.prio_young = p->knob_prio_young;
-        // stream seams inside the launch (seam_epilogue) or in a launch of their own: UPX_SEAM_INKERNEL = 1 always, 2 (default)
+        // stream seams inside the launch (seam_epilogue; experiment, default off: the agent-scope release / acquire it needs costs more
+        // than the launch it saves - c1 0.030 -> 0.070 ms, C3 fused launches +40 %) or in a launch of their own: UPX_SEAM_INKERNEL = 1 always, 2
         // when the launch does not fill the chip - a short signal, where the seam launch is a sixth of the step -, 0 never
         const bool seam_inside = n_streams > 1 && p->d_pair_cnt && n_wg <= (long long)p->pair_cnt_n &&
                                  (p->knob_seam_inkernel == 1 || (p->knob_seam_inkernel == 2 && n_wg <= slots));
