@@ -358,6 +358,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=None, help="audio per GPU / per track (default: the workload's)")
     ap.add_argument("--preheat-ms", type=float, default=200.0,
                     help="untimed steps for this long before the W warm-up steps: the card leaves its idle power state")
+    ap.add_argument("--no-reserve", action="store_true",
+                    help="skip upx_plan_reserve (its tiny warm-up call launches every kernel once on a short signal, which would "
+                         "dilute per-kernel averages of a profiler run that only sees a few launches: scripts/pmc.sh, prof.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive side measurements")
     args = ap.parse_args()
@@ -470,7 +473,8 @@ def main():
 
     # the first call of a shape otherwise allocates its seam / scratch buffers and uploads its stream tables on the way
     # (synchronising calls): prepared up front, so that what the first steps cost beyond a steady step is the card's clocks
-    plan.reserve(*((nominal, nominal, nominal) if batch else (t_in, own, t_out)))
+    if not args.no_reserve:
+        plan.reserve(*((nominal, nominal, nominal) if batch else (t_in, own, t_out)))
 
     def barrier():
         if hasattr(comm, "wait"):
@@ -539,7 +543,7 @@ def main():
     # host work of one process_device call (launch geometry, stream tables: std::vector work per call): the same code path
     # without the launches (upx_plan_reserve's dry run + one synchronisation of the idle stream)
     prep_us = None
-    if world == 1:
+    if world == 1 and not args.no_reserve:
         shape = (nominal, nominal, nominal) if batch else (t_in, own, t_out)
         plan.sync()
         t_h = time.perf_counter()
@@ -549,7 +553,7 @@ def main():
     # what a pass with these kernels' lane pattern (4 bytes per lane, grid-stride) reaches on this card, measured in this
     # run: x *= 1.0f over one output plane (upx_scale: one load and one store per sample, values unchanged)
     stream_gbps = None
-    if world == 1 and not batch:
+    if world == 1 and not batch and not args.no_reserve:
         n_probe = int(own)
         for _ in range(3):
             plan.scale(d_out[0], n_probe, 1.0)

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --preheat-ms 0 --no-cpu-baseline --no-e2e $BENCH_ARGS > $OUT/$name.json 2> $OUT/$name.err || echo "pmc $name failed"
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --preheat-ms 0 --no-cpu-baseline --no-e2e --no-reserve $BENCH_ARGS > $OUT/$name.json 2> $OUT/$name.err || echo "pmc $name failed"
 }
 BENCH_ARGS="$*"
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY

@@ -5,7 +5,7 @@ TAG=${1:-r02}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e "$@" > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e --no-reserve "$@" > $OUT/bench.json 2> $OUT/bench.err
 f=$(ls -t $OUT/*/*kernel_stats.csv | head -1)
 cp $f $OUT/kernel_stats.csv
 python3 - "$f" <<'PY'
