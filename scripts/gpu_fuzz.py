@@ -40,7 +40,15 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
         continue
     x = orc.synthetic_stereo(total, (11, trial))
     ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
-    got = ux.extract_center_left_right_multi_band_in_memory(x[:, 0], x[:, 1], 44100, gb)
+    # the drop-in entry on the caller's own arrays (upx_process_lr): float32 column views, float64 column views (main.py:49-50),
+    # two contiguous float64 arrays - in turn; the cast and the interleave happen on the device
+    kind = trial % 3
+    if kind == 0:
+        L, R = x[:, 0], x[:, 1]
+    else:
+        x64 = x.astype(np.float64)
+        L, R = (x64[:, 0], x64[:, 1]) if kind == 1 else (x64[:, 0].copy(), x64[:, 1].copy())
+    got = ux.extract_center_left_right_multi_band_in_memory(L, R, 44100, gb)
     errs = [rms(g.astype(np.float64) - r) for g, r in zip(got, ref)]
     plan = ux.DevicePlan(gb)
     try:
