@@ -276,6 +276,17 @@ def test_c3_full_size_windows_vs_oracle(ux, orc, c3_full):
         close(got[a + 8192:], r[8192:])
 
 
+def test_c3_full_size_float64_views_equal_the_float32_call(ux, orc, c3_full):
+    """BASELINE configs[2] at full size through the documented drop-in call: a float64 [T, 2] parent, its two column views
+    (main.py:49-50), seven streamed chunks, cast + interleave on the device - bit for bit the planes of the float32 call."""
+    x, bands, out = c3_full
+    wave = x.astype(np.float64)
+    got = ux.extract_center_left_right_multi_band_in_memory(wave[:, 0], wave[:, 1], 48000, bands)
+    for g, o in zip(got, out):
+        assert g.dtype == np.float32 and np.array_equal(g, o)
+    del wave
+
+
 def test_c3_properties_full_size(ux, orc, c3_full):
     x, bands, out = c3_full
     total = len(x)
