@@ -563,6 +563,24 @@ def test_rccl_single_rank_communicator(ux, orc):
         want = h.copy()
         want[:spill] += h[own:own + spill]
         assert np.array_equal(got, want)
+    # the timeout path of upx_comm_wait: an exchange queued behind ~0.2 s of other work on the plan's stream has not run when a
+    # 5 ms wait expires - as if a peer had not arrived - so the communicator is aborted and the call says so
+    x = orc.synthetic_stereo(2_000_000, 3)
+    d_in = plan.alloc(x.shape[0] * 8)
+    planes = [plan.alloc(x.shape[0] * 4) for _ in range(3)]
+    plan.h2d(d_in, x)
+    plan.sync()
+    for _ in range(400):
+        plan.process_device(d_in, x.shape[0], x.shape[0], planes[0], planes[1], planes[2], x.shape[0])
+    seam.selftest(d, own, spill, 8, 5)
+    import time
+    t0 = time.perf_counter()
+    with pytest.raises(Exception, match="did not finish within|aborted"):
+        seam.wait(0.005)
+    assert time.perf_counter() - t0 < 5.0
+    plan.sync()                           # the stream itself drains: nothing is left hanging
+    for p in planes + [d_in]:
+        plan.free(p)
     # the abort path: the communicator is gone afterwards and says so (a rank whose peer never arrived ends here)
     seam.abort()
     seam.abort()                          # idempotent
