@@ -192,3 +192,48 @@ def test_long_files_fall_back_to_the_host_flow_when_the_plan_cannot_chunk(tmp_pa
     monkeypatch.setattr(cli, "extract_center_left_right_multi_band_in_memory", host_extract)
     with pytest.raises(RuntimeError, match="host flow reached"):
         cli.run("a.wav", "stereo_sum", str(tmp_path / "in"), str(tmp_path / "out"))
+
+
+def test_drop_in_entry_dispatch_takes_views_as_they_are(monkeypatch):
+    """DevicePlan.process_lr (the host side of upx_process_lr) without a GPU: which arrays go to the library as they are - float64 /
+    float32 column views of one [T, 2] parent (stride 2), two contiguous arrays (stride 1) - and which are cast on the host first."""
+    import threading
+    import numpy as np
+    from upmix_amd import _lib, extractor, hostmem
+
+    calls = []
+
+    class FakeLib:
+        def upx_process_lr(self, handle, left, right, fmt, stride, n, *outs):
+            calls.append(("lr", left.value, right.value, fmt, stride, n))
+            return 0
+
+    plan = extractor.DevicePlan.__new__(extractor.DevicePlan)
+    plan._lib, plan.handle, plan.lock = FakeLib(), 1, threading.RLock()
+    plan.process = lambda x: calls.append(("host", x.dtype, x.shape, bool(x.flags.c_contiguous))) or ("c", "l", "r")
+    monkeypatch.setattr(hostmem, "empty", lambda n, dt, handle, lazy=0: np.empty(n, dt))
+    wave = np.arange(20, dtype=np.float64).reshape(10, 2)
+    plan.process_lr(wave[:, 0], wave[:, 1])                              # main.py:49-50
+    assert calls[-1] == ("lr", wave.ctypes.data, wave.ctypes.data + 8, _lib.SAMPLE_F64, 2, 10)
+    w32 = wave.astype(np.float32)
+    plan.process_lr(w32[:, 0], w32[:, 1])
+    assert calls[-1] == ("lr", w32.ctypes.data, w32.ctypes.data + 4, _lib.SAMPLE_F32, 2, 10)
+    a, b = wave[:, 0].copy(), wave[:, 1].copy()
+    plan.process_lr(a, b)
+    assert calls[-1] == ("lr", a.ctypes.data, b.ctypes.data, _lib.SAMPLE_F64, 1, 10)
+    plan.process_lr(a, a)                                                 # mono duplicated (main.py:47-48): the same array twice
+    assert calls[-1][:3] == ("lr", a.ctypes.data, a.ctypes.data) and calls[-1][4] == 1
+    for L, R in ((wave[:, 1], wave[:, 0]),                                # columns swapped: not "right = left + one element"
+                 (wave[::2, 0], wave[::2, 1]),                            # every other frame: stride 4
+                 (a, b.astype(np.float32)),                               # mixed dtypes
+                 (a.astype(np.int16), b.astype(np.int16)),                # integers
+                 (a.astype(">f8"), b.astype(">f8"))):                     # foreign byte order
+        plan.process_lr(L, R)
+        assert calls[-1][0] == "host" and calls[-1][1] == np.float32 and calls[-1][2] == (len(L), 2) and calls[-1][3], (L, R)
+    plan.process_lr(list(a), list(b))                                     # anything array-like (center_extraction.py:477-482): float64 arrays
+    assert calls[-1][0] == "lr" and calls[-1][3:] == (_lib.SAMPLE_F64, 1, 10)
+    with pytest.raises(ValueError):
+        plan.process_lr(a, b[:-1])
+    with pytest.raises(ValueError):
+        plan.process_lr(wave, wave)
+    plan.handle = None                                                   # (nothing to destroy)
