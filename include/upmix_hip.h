@@ -69,6 +69,19 @@ int upx_supported(int32_t block_size, int32_t hop);
  */
 int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* block_size, const int32_t* hop,
                     const float* w_analysis, const float* w_synthesis, const float* gain);
+
+/*
+ * What upx_plan_create would SELECT for these bands, without a device: for every band the kernel(s) of the launch that
+ * carries it, one line per band in `names` ("analysis|synthesis" for a band-limited group; merged bands repeat their
+ * group's line).  Same arguments as upx_plan_create; n = size of `names` (UPX_ERR_INVALID when too small).
+ *
+ * Environment: the library reads its UPX_* tuning / test knobs (launch geometry, kernel family, chunk lengths - DESIGN.md,
+ * "Knobs") at plan creation ONLY in a process that opts in with UPX_TUNING=1; without it no variable changes which kernels
+ * run, how a signal is cut, or a single bit of the result.  The band sum is always the reference's ((0 + b0) + b1) + ...
+ * (center_extraction.py:508-511); the experiments that once reordered it exist in -DUPX_EXPERIMENTS builds only.
+ */
+int upx_plan_kernel_names(int n_bands, const int32_t* block_size, const int32_t* hop, const float* w_analysis,
+                          const float* w_synthesis, const float* gain, char* names, size_t n);
 void upx_plan_destroy(upx_plan* plan);
 
 /* Tuning: hop-blocks each stream walks (0 = automatic).  band = -1 sets all bands. */
@@ -151,8 +164,12 @@ int upx_process_device(upx_plan* plan, const float* d_stereo, int64_t t_in, int6
  * Prepares the plan for upx_process_device calls of this shape: launch geometry, stream tables (uploaded), seam and
  * scratch buffers - everything the FIRST call of a shape otherwise allocates, uploads and synchronises for on the way
  * (a few tenths of a millisecond: the software part of a cold call; the rest of a cold call is the card's clock ramp).
- * Launches nothing and touches no signal buffer.  A later upx_process_device(plan, ., t_in, own_len, ., ., ., t_out) then
- * only enqueues kernels.  Blocking.  The reference has no counterpart (its state is built in
+ * Touches no buffer of the caller's.  The FIRST reserve of a plan also runs one tiny warm-up call through every kernel of
+ * the plan (a few frames of silence in a temporary device allocation it frees again), so that the runtime's per-kernel set-up
+ * is not paid by the caller's first step either; every reserve then walks the geometry of the shape asked for WITHOUT
+ * launching.  Neither leaves a trace in the timing rings or in the band / launch reports (upx_plan_band_times_*,
+ * upx_plan_band_info, upx_plan_band_fill keep describing the caller's own calls).  A later upx_process_device(plan, ., t_in,
+ * own_len, ., ., ., t_out) then only enqueues kernels.  Blocking.  The reference has no counterpart (its state is built in
  * MultiBandExtractorAccu.__init__, center_extraction.py:240-271, which upx_plan_create mirrors).
  */
 int upx_plan_reserve(upx_plan* plan, int64_t t_in, int64_t own_len, int64_t t_out);

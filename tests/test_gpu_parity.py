@@ -397,12 +397,9 @@ def test_results_live_in_pooled_page_locked_memory(ux, orc, monkeypatch):
     # (earlier tests of this process may have asked for the same size class: forget that, and count pinned bytes from here)
     # ... and left idle blocks of it behind, which any call may use: release them)
     gc.collect()
-    with hostmem.POOL._lock:
-        hostmem.POOL._release_idle(plan.handle)
-        hostmem.POOL._asked.clear()
-    held0 = hostmem.POOL._held
+    held0 = hostmem.POOL.reset_for_tests(plan.handle)["held"]
     first = plan.process(x)
-    assert not any(hostmem.is_pinned(o) for o in first) and hostmem.POOL._held == held0
+    assert not any(hostmem.is_pinned(o) for o in first) and hostmem.POOL.pinned_bytes() == held0
     a = plan.process(x)
     assert all(hostmem.is_pinned(o) for o in a) and all(np.array_equal(o, q) for o, q in zip(a, first))
     del first
@@ -417,12 +414,12 @@ def test_results_live_in_pooled_page_locked_memory(ux, orc, monkeypatch):
     c = plan.process(x)                                # the freed blocks come back (two of them: one is still viewed)
     assert len(addr & {o.ctypes.data for o in c}) == 2
     assert np.array_equal(view, keep[0][1000:2000]) and all(np.array_equal(o, k) for o, k in zip(c, keep))
-    held = hostmem.POOL._held
+    held = hostmem.POOL.pinned_bytes()
     assert held - held0 >= 5 * 300000 * 4              # at least the live planes of this test are pinned (b, c, the viewed block of a)
     # a pool without room hands out pageable arrays; the numbers do not change
     monkeypatch.setattr(hostmem.POOL, "limit", 0)
     d = plan.process(x)
-    assert all(np.array_equal(o, k) for o, k in zip(d, keep)) and hostmem.POOL._held == held
+    assert all(np.array_equal(o, k) for o, k in zip(d, keep)) and hostmem.POOL.pinned_bytes() == held
     left = c[1]
     left *= 2.0                                        # results are the caller's to scale in place (main.py:95-97)
     assert np.array_equal(c[1], keep[1] * np.float32(2.0))
@@ -514,26 +511,56 @@ def test_plan_reserve_prepares_a_call_shape(ux, orc):
         ux.DevicePlan(bands).reserve(-1, 0, 0)
 
 
-def test_dual_stream_experiment_kernels_agree(ux, orc, monkeypatch):
-    """UPX_DUAL=1 (round-5 experiment, upx_reg_fused_dual.hip): two stream sets per wave at one wave per SIMD run the same
-    phases on the same data - bit-identical planes to the default kernels except the float32 association on the blocks
-    behind stream seams (the stream cut differs)."""
-    x = orc.synthetic_stereo(1200000, 8)
+POISON = {"UPX_FIRST_BAND": "4", "UPX_BAND_ROTATE": "2", "UPX_DUAL": "1", "UPX_SEAM_INKERNEL": "1", "UPX_KERNEL_VARIANT": "2",
+          "UPX_N_CU": "128", "UPX_FORCE_UNFUSED": "1", "UPX_ZOOM": "0", "UPX_EDGE_PERCENT": "60", "UPX_ZOOM_ONCE": "0",
+          "UPX_NO_BAND_MERGE": "1", "UPX_NO_LIVE_FLAVOUR": "1", "UPX_STREAM_CHUNK": "50000", "UPX_PRIO_YOUNG": "0",
+          "UPX_ZOOM_SCRATCH_MB": "1", "UPX_MIN_STREAM_FRAMES": "16", "UPX_SEAM_VEC": "0"}
+
+
+def test_a_poisoned_environment_changes_neither_kernels_nor_bits(ux, orc, monkeypatch):
+    """round 5's library read ~37 UPX_* variables at plan creation, among them experiments that
+    changed the band-sum association (UPX_FIRST_BAND, UPX_BAND_ROTATE) and swapped in kernels no BASELINE test covers
+    (UPX_DUAL, UPX_SEAM_INKERNEL, UPX_KERNEL_VARIANT).  The experiments are compiled out of the product library now
+    (-DUPX_EXPERIMENTS builds only) and every remaining knob is read only in a process that opts in with UPX_TUNING=1: without
+    it, whatever the environment holds, a plan selects the same kernels, cuts the same streams and returns the same bits -
+    on the drop-in entry and on the streamed host call alike."""
+    x = orc.synthetic_stereo(700000, 8)
     edges = [0, 30, 120, 480, 1920, 7680]
-    outs, names = {}, {}
-    for dual in ("0", "1"):
-        monkeypatch.setenv("UPX_DUAL", dual)
+
+    def run():
         bands = gpu_chain(ux, edges, 48000, 8192, 32)
         plan = ux.DevicePlan(bands)
-        names[dual] = [plan.band_kernel_name(i) for i in range(len(bands))]
-        outs[dual] = plan.process(x)
+        names = [(plan.band_kernel_name(i), plan.band_phase_kernel_name(i, 0), plan.band_phase_kernel_name(i, 1))
+                 for i in range(len(bands))]
+        out = plan.process(x)
+        info = [plan.band_info(i) for i in range(len(bands))]
         plan.close()
-    assert sum("dual" in n for n in names["1"]) == 2 and not any("dual" in n for n in names["0"])
-    ref_bands = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, 48000, max_block_size=8192, threshold_factor=32)
-    ref = orc.extract_multi_band(x[:60000, 0].astype(np.float64), x[:60000, 1].astype(np.float64), ref_bands)
-    for a, b, r in zip(outs["0"], outs["1"], ref):
-        assert rms(a.astype(np.float64) - b) < 1e-7
-        close(b[:50000], r[:50000])
+        wave = x.astype(np.float64)
+        entry = ux.extract_center_left_right_multi_band_in_memory(wave[:, 0], wave[:, 1], 48000, bands)
+        return names, info, out, entry
+
+    monkeypatch.delenv("UPX_TUNING")
+    clean = run()
+    for k, v in POISON.items():
+        monkeypatch.setenv(k, v)
+    dirty = run()
+    assert clean[0] == dirty[0] and clean[1] == dirty[1]
+    assert not any("dual" in n or "Cfg<13, 4, 16>" in n for row in dirty[0] for n in row)
+    for a, b in zip(clean[2] + clean[3], dirty[2] + dirty[3]):
+        assert np.array_equal(a, b)
+    # ... and the same variables DO reach an opted-in process (the gate is the opt-in, not deaf knobs): the unfused pipeline
+    # as a second implementation, within rounding of the default kernels
+    monkeypatch.setenv("UPX_TUNING", "1")
+    for k in POISON:
+        monkeypatch.delenv(k)
+    monkeypatch.setenv("UPX_FORCE_UNFUSED", "1")
+    bands = gpu_chain(ux, edges, 48000, 8192, 32)
+    plan = ux.DevicePlan(bands)
+    assert all("big" in plan.band_kernel_name(i) for i in range(len(bands)))
+    forced = plan.process(x)
+    plan.close()
+    for a, b in zip(clean[2], forced):
+        assert not np.array_equal(a, b) and rms(a.astype(np.float64) - b) < 1e-7
 
 
 def test_rccl_single_rank_communicator(ux, orc):
@@ -834,18 +861,18 @@ def test_pathological_signals(ux, orc):
 
 
 def test_kernel_flavours_agree(ux, orc, monkeypatch):
-    """Wide streams (the fused kernel for STFT 4096 / 8192), the plain Stockham schedule (UPX_KERNEL_VARIANT=2), the
-    8-points-per-lane kernels (=1) and the band-limited two-kernel path (upx_zoom.h; UPX_ZOOM = smallest decimation
-    that takes it, 0 = never) are different routings of the same arithmetic: each within tolerance of the oracle,
-    and within float32 rounding of one another."""
+    """Wide streams (the fused kernel for STFT 4096 / 8192) and the band-limited two-kernel path (upx_zoom.h; UPX_ZOOM =
+    smallest decimation that takes it, 0 = never) are different routings of the same arithmetic: each within tolerance of
+    the oracle, and within float32 rounding of one another.  (The plain Stockham schedule and the 8-points-per-lane
+    kernels of rounds 1-5 live in experiment builds only: csrc/experiments/.)"""
     x = orc.synthetic_stereo(150000, 21)
     edges, tf = [0, 120, 480, 4000], 32
     ref_bands = orc.plan_bands(edges, 0.75, orc.win_blackman_harris, 48000, max_block_size=8192, threshold_factor=tf)
     assert sorted({b.block_size for b in ref_bands}) == [512, 4096, 8192]
     ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ref_bands)
     outs, names = {}, {}
-    for variant, zoom in (("0", "0"), ("2", "0"), ("1", "0"), ("default", None)):
-        monkeypatch.setenv("UPX_KERNEL_VARIANT", variant if variant in "012" else "0")
+    for variant, zoom in (("0", "0"), ("default", None)):
+        monkeypatch.setenv("UPX_KERNEL_VARIANT", "2")        # deaf in the product library: no such kernels in it
         if zoom is None:
             monkeypatch.delenv("UPX_ZOOM", raising=False)
         else:
@@ -858,15 +885,12 @@ def test_kernel_flavours_agree(ux, orc, monkeypatch):
         for got, r in zip(outs[variant], ref):
             close(got, r)
     assert any("WideCfg<13, 4>" in n for n in names["0"]) and any("WideCfg<12, 4>" in n for n in names["0"])
-    assert not any("Wide" in n for n in names["2"]) and any("Cfg<13, 4, 16>" in n for n in names["2"])
-    assert any("Cfg<13, 4, 8>" in n for n in names["1"])
     # default: the merged 8192 bands (pass band below bin 128: P = 256, D = 32) take the band-limited path,
     # the 4096 band (bins up to 426: P = 1024, D = 4: below the smallest decimation the path is built for) stays fused
     assert any("zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 4>>" in n for n in names["default"])
     assert any("WideCfg<12, 4>" in n for n in names["default"])
-    for v in ("2", "1", "default"):
-        for a, b in zip(outs["0"], outs[v]):
-            assert rms(a.astype(np.float64) - b) < 1e-7
+    for a, b in zip(outs["0"], outs["default"]):
+        assert rms(a.astype(np.float64) - b) < 1e-7
 
 
 def test_streamed_host_call(ux, orc, monkeypatch):

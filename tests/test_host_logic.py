@@ -176,7 +176,8 @@ def test_long_files_fall_back_to_the_host_flow_when_the_plan_cannot_chunk(tmp_pa
     assert cli.codec_can_take(cli.LAUNCH_FRAMES - 1, odd, {})
     assert cli.codec_can_take(cli.LAUNCH_FRAMES, pow2, {}) and cli.codec_can_take(10 * cli.LAUNCH_FRAMES, pow2, {"UPX_WAV_CHUNK": "4194304"})
     assert not cli.codec_can_take(cli.LAUNCH_FRAMES, odd, {})
-    assert not cli.codec_can_take(cli.LAUNCH_FRAMES, pow2, {"UPX_WAV_CHUNK": "0"})
+    assert not cli.codec_can_take(cli.LAUNCH_FRAMES, pow2, {"UPX_WAV_CHUNK": "0", "UPX_TUNING": "1"})
+    assert cli.codec_can_take(cli.LAUNCH_FRAMES, pow2, {"UPX_WAV_CHUNK": "0"})      # the library ignores knobs without UPX_TUNING=1
     # run() falls through to the host flow when the codec declines (a short file + a lowered launch limit stand in for 2^29 frames)
     import numpy as np
     from upmix_amd import wav
@@ -237,3 +238,96 @@ def test_drop_in_entry_dispatch_takes_views_as_they_are(monkeypatch):
     with pytest.raises(ValueError):
         plan.process_lr(wave, wave)
     plan.handle = None                                                   # (nothing to destroy)
+
+
+def test_band_signature_is_memoised_and_follows_attribute_assignment():
+    """the plan-cache key hashed both windows of every band on EVERY drop-in call (0.17 ms for the C3
+    plan, 0.7 ms for the default plan).  It is kept on the extractor now and dropped when an attribute it is made of is
+    assigned; in-place edits of the window arrays - which no key could notice - raise instead of leaving a stale plan."""
+    import time
+    from upmix_amd import extractor as ex
+    bands = ux.chain_bands([0, 300, 3000], 0.75, ux.make_blackman_harris, 48000, max_block_size=65536, verbose=False)
+    sig0 = tuple(ex._band_signature(b) for b in bands)
+    assert all("_signature" in b.__dict__ for b in bands)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        key = (tuple(ex._band_signature(b) for b in bands), 0, ex._env_knobs())
+    per_call_us = (time.perf_counter() - t0) / 200 * 1e6
+    assert key[0] == sig0
+    assert per_call_us < 200, per_call_us          # 20 us asked on the GPU box's host; this container is several times slower
+    b = bands[1]
+    for name, value in (("f_low", b.f_low + 1.0), ("xover_mode", "hard_zero"), ("analysis_window", ux.make_hann(b.block_size)),
+                        ("synthesis_window", np.ones(b.block_size, np.float32)), ("xover_width_high_hz", 1.0)):
+        before = ex._band_signature(b)
+        setattr(b, name, value)
+        assert "_signature" not in b.__dict__
+        assert ex._band_signature(b) != before, name
+    with pytest.raises(ValueError):
+        b.analysis_window[:] = 0                   # would otherwise keep the plan of the old window, silently
+    w = b.analysis_window.copy()
+    w[0] = 0.5
+    b.analysis_window = w                          # whole-attribute assignment is the supported way and re-keys
+    assert ex._band_signature(b)[-2] == hash(w.astype(np.float32).tobytes())
+
+
+def test_env_knobs_key_sees_upx_variables_only(monkeypatch):
+    from upmix_amd import extractor as ex
+    base = ex._env_knobs()
+    monkeypatch.setenv("NOT_OURS", "1")
+    assert ex._env_knobs() == base
+    monkeypatch.setenv("UPX_FORCE_UNFUSED", "1")
+    assert ex._env_knobs() != base
+    monkeypatch.delenv("UPX_FORCE_UNFUSED")
+    assert ex._env_knobs() == base
+
+
+C3_EDGES = [0, 30, 120, 480, 1920, 7680]
+POISON = {"UPX_FIRST_BAND": "4", "UPX_BAND_ROTATE": "2", "UPX_DUAL": "1", "UPX_SEAM_INKERNEL": "1", "UPX_KERNEL_VARIANT": "2",
+          "UPX_N_CU": "128", "UPX_FORCE_UNFUSED": "1", "UPX_ZOOM": "0", "UPX_NO_BAND_MERGE": "1", "UPX_NO_LIVE_FLAVOUR": "1",
+          "UPX_NO_SINGLE_FLAVOUR": "1", "UPX_ZOOM_A_RG": "16"}
+
+
+def test_kernel_selection_is_deaf_to_the_environment_unless_the_process_opts_in(monkeypatch):
+    """plan creation under a poisoned environment selects the same kernels (upx_plan_kernel_names = the
+    selection half of upx_plan_create, no device needed).  Every BASELINE plan + the reference's default plan."""
+    from upmix_amd import extractor as ex
+    plans = {
+        "c3": ux.chain_bands(C3_EDGES, 0.75, ux.make_blackman_harris, 48000, max_block_size=8192, verbose=False),
+        "default": ux.chain_bands(C3_EDGES, 0.75, ux.make_blackman_harris, 48000, verbose=False),
+        "c4": ux.chain_bands(C3_EDGES, 0.75, ux.make_blackman_harris, 96000, max_block_size=8192, verbose=False),
+        "c2": ux.chain_bands([0, 300, 3000], 0.75, ux.make_blackman_harris, 48000, max_block_size=4096, threshold_factor=64,
+                             verbose=False),
+    }
+    monkeypatch.delenv("UPX_TUNING")
+    clean = {k: ex.plan_kernel_names(v) for k, v in plans.items()}
+    # what the six C3 bands run (DESIGN.md, kernel families): one merged band-limited pair for the three 8192 bands, a pair
+    # for the 4096 band, live-slot fused kernel at 1024, single-band fused kernel at 256
+    assert clean["c3"][0] == clean["c3"][1] == clean["c3"][2]
+    assert "upx_zoom_analysis_kernel<upx::ZoomCfg<8, 16, 4>>|upx_zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 4>>" == clean["c3"][0]
+    assert clean["c3"][3] == "upx_zoom_analysis_kernel<upx::ZoomCfg<9, 8, 4>>|upx_zoom_synthesis_kernel<upx::ZoomCfg<9, 8, 4>>"
+    assert clean["c3"][4] == "upx_band_kernel<upx::Cfg<10, 4, 16>, 2, false, upx::Live<0, 4>>"
+    assert clean["c3"][5] == "upx_band_kernel<upx::Cfg<8, 4, 16>, 2, false>"
+    for k, v in POISON.items():
+        monkeypatch.setenv(k, v)
+    assert {k: ex.plan_kernel_names(v) for k, v in plans.items()} == clean
+    # the same variables in a process that opted in: the knobs are heard (the library is not deaf, the default is)
+    monkeypatch.setenv("UPX_TUNING", "1")
+    heard = ex.plan_kernel_names(plans["c3"])
+    assert all("upx_big pipeline" in n for n in heard)
+    # ... but the experiments are not in this library at all: UPX_KERNEL_VARIANT / UPX_DUAL select nothing even then
+    for k in ("UPX_FORCE_UNFUSED", "UPX_ZOOM", "UPX_NO_BAND_MERGE", "UPX_NO_LIVE_FLAVOUR", "UPX_NO_SINGLE_FLAVOUR", "UPX_ZOOM_A_RG"):
+        monkeypatch.delenv(k)
+    assert ex.plan_kernel_names(plans["c3"]) == clean["c3"]
+
+
+def test_experiment_kernels_are_not_in_the_product_library():
+    """The rejected experiments (8 points per lane, plain schedule, dual-stream wave, in-kernel seams) are compiled only into
+    -DUPX_EXPERIMENTS builds (csrc/experiments/): the shipped library holds no such kernel and no such knob."""
+    res = json.load(open(os.path.join(ROOT, "upmix_amd", "csrc", "build", "kernel_resources.json")))
+    assert res and not any("dual" in k or ", 8>, 4>" in k for k in res), [k for k in res if "dual" in k]
+    assert not any(v.get("unit", "").startswith("upx_exp_") for v in res.values())
+    blob = open(os.path.join(ROOT, "upmix_amd", "libupmix_hip.so"), "rb").read()
+    for name in (b"UPX_DUAL", b"UPX_FIRST_BAND", b"UPX_BAND_ROTATE", b"UPX_SEAM_INKERNEL", b"UPX_N_CU", b"UPX_KERNEL_VARIANT"):
+        assert name not in blob, name
+    src = os.listdir(os.path.join(ROOT, "upmix_amd", "csrc"))
+    assert not any(f.startswith("upx_reg_") and any(t in f for t in ("dual", "p8", "plain")) for f in src)

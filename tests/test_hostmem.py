@@ -172,3 +172,37 @@ def test_default_limit_scales_with_ram_and_ranks(tmp_path):
     assert hostmem.default_limit({"WORLD_SIZE": "8"}, str(info)) == 4096 << 20   # eight ranks: 128 / 4 / 8 = 4 GiB each
     assert hostmem.default_limit({"WORLD_SIZE": "8", "LOCAL_WORLD_SIZE": "2"}, str(info)) == 8192 << 20
     assert hostmem.default_limit({}, str(tmp_path / "absent")) == 8192 << 20
+
+
+def test_lazy_first_call_marks_plans_live_and_asked_is_bounded(monkeypatch):
+    """Round-5 advisor findings: (1) the lazy path returned before `plans_live` was set back to True, so the sweeper of an
+    earlier idle period could keep running against a new plan's first call; (2) `_asked` grew by one entry per distinct
+    size for ever (a directory of tracks: every result size differs)."""
+    pool, fake = make_pool(monkeypatch, 1 << 40)
+    pool.plans_live = False                          # as trim() leaves it when the process' last plan closes
+    tok = pool.new_call()
+    first = pool.take(1000, "plan", lazy=tok)
+    assert pool.plans_live and first.base is None and fake.allocs == 0     # pageable array, and a plan is alive again
+    g = hostmem._GRANULE
+    for k in range(2, pool._ASKED_MAX + 50):
+        pool.take(k * g, "plan", lazy=pool.new_call())
+    assert len(pool._asked) <= pool._ASKED_MAX and fake.allocs == 0
+    second = pool.take(1000 + 5, "plan", lazy=pool.new_call())             # same capacity class, but aged out: asks again
+    assert second.base is None
+    third = pool.take(1000, "plan", lazy=pool.new_call())                  # now it has been asked for twice: pinned
+    assert hostmem.is_pinned(third) and fake.allocs == 1
+
+
+def test_reset_for_tests_is_a_fresh_process_for_the_pool(monkeypatch):
+    pool, fake = make_pool(monkeypatch, 64 << 20)
+    kept = pool.take(1000, None)
+    idle = pool.take(1000, None)
+    pool.take(5 << 20, None, lazy=pool.new_call())
+    del idle
+    gc.collect()
+    g = hostmem._GRANULE
+    assert pool.pinned_bytes() == 2 * g
+    r = pool.reset_for_tests(None)
+    assert r == {"held": g, "idle_released": g} and fake.frees == 1 and pool.pinned_bytes() == g and not pool._asked
+    assert pool.take(5 << 20, None, lazy=pool.new_call()).base is None     # first of its size again
+    del kept

@@ -97,7 +97,11 @@ def test_product_path_does_not_import_torch():
                                                if f.endswith(".py")]
     for path in files:
         text = open(path).read()
-        assert "import torch" not in text and "os._exit" not in text, path
+        assert "import torch" not in text, path
+        # nobody leaves through os._exit - except the watchdog's last resort (sharding._Watchdog._fire: SIGTERM first, and only
+        # when a host application's handler swallowed it, round-5 advisor finding)
+        n_exit = sum("os._exit(" in line and not line.lstrip().startswith("#") for line in text.splitlines())
+        assert n_exit == (1 if path.endswith(os.path.join("upmix_amd", "sharding.py")) else 0), path
 
 
 def _join(rank, world, port, n_ports, q):

@@ -112,6 +112,30 @@ def _stuck_in_a_collective(seconds):
         time.sleep(60)      # stands for the blocking init a peer never joins
 
 
+def _stuck_with_a_sigterm_handler(seconds):
+    import signal
+    import time
+    from upmix_amd import sharding as sh
+    # an embedding application's handler: Python would run it on the main thread, which never comes back from the C call
+    signal.signal(signal.SIGTERM, lambda *_: None)
+    with sh._Watchdog(seconds, "rank 0: ncclCommInitRank", grace=0.5):
+        # a blocking call that signals do not interrupt (time.sleep resumes after a handled signal, PEP 475), like the C call
+        time.sleep(60)
+
+
+def test_watchdog_ends_the_process_even_when_the_application_handles_sigterm():
+    """ADVICE r5: with a Python SIGTERM handler installed and the main thread blocked, SIGTERM alone never ends the process;
+    after the grace period the watchdog leaves through os._exit(143)."""
+    import multiprocessing
+    import time
+    ctx = multiprocessing.get_context("spawn")
+    p = ctx.Process(target=_stuck_with_a_sigterm_handler, args=(0.5,))
+    t0 = time.monotonic()
+    p.start()
+    p.join(30)
+    assert p.exitcode == 143 and time.monotonic() - t0 < 25, p.exitcode
+
+
 def test_watchdog_ends_a_process_stuck_in_a_blocking_collective():
     """RCCL's blocking init has no error path: when a peer never arrives, the watchdog ends the process (non-zero) instead of
     letting it wait for ever; a body that returns in time cancels it."""

@@ -37,6 +37,7 @@ SIGNATURES = {
     "upx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "upx_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "upx_plan_create": (C.c_int, [vpp, C.c_int, C.c_int, i32p, i32p, f32p, f32p, f32p]),
+    "upx_plan_kernel_names": (C.c_int, [C.c_int, i32p, i32p, f32p, f32p, f32p, C.c_char_p, C.c_size_t]),
     "upx_plan_destroy": (None, [C.c_void_p]),
     "upx_plan_set_blocks_per_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "upx_process": (C.c_int, [C.c_void_p, f32p, C.c_int64, f32p, f32p, f32p]),

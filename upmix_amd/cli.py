@@ -104,13 +104,15 @@ def codec_can_take(n_frames: int, band_extractors, env=os.environ) -> bool:
     """
     Whether upx_wav_pipeline / upx_wav_shard_open accepts a file of n_frames: files of 2^29 frames or more run in chunks
     on the plan's shard grid, which needs hops that share one (every hop divides the largest; overlaps that are not
-    powers of two do not) and the chunk schedule switched on (UPX_WAV_CHUNK != 0).  Otherwise the library answers
-    UPX_ERR_INVALID, and the callers take the host flow instead of aborting the run.
+    powers of two do not) and the chunk schedule switched on (it always is, unless a process that opted into the tuning
+    knobs with UPX_TUNING=1 set UPX_WAV_CHUNK=0).  Otherwise the library answers UPX_ERR_INVALID, and the callers take the
+    host flow instead of aborting the run.
     """
     if n_frames < LAUNCH_FRAMES:
         return True
     hops = [int(b.hop_size) for b in band_extractors]
-    return all(max(hops) % h == 0 for h in hops) and str(env.get("UPX_WAV_CHUNK", "")).strip() != "0"
+    chunks_off = str(env.get("UPX_TUNING", "")).strip() == "1" and str(env.get("UPX_WAV_CHUNK", "")).strip() == "0"
+    return all(max(hops) % h == 0 for h in hops) and not chunks_off
 
 
 def _print_plan(band_extractors) -> None:

@@ -1,4 +1,4 @@
-// upx_reg_fused_dual.hip - EXPERIMENT (round 5): the fused streaming kernel with TWO stream sets per wave.
+// experiments/upx_exp_fused_dual.hip - EXPERIMENT (round 5): the fused streaming kernel with TWO stream sets per wave.
 // A lane hosts V = 2 virtual threads (tid, tid + real workgroup size), each with its own register state and LDS buffer,
 // and a phase runs them one after the other inside ONE basic block, so the compiler may interleave the two independent
 // instruction streams; one wave per SIMD (launch bounds 1: 512 registers per lane, what does not fit the 256 architectural
@@ -8,7 +8,10 @@
 #if defined(UPX_DUAL_NO_FENCE)
 #define UPX_NO_SCHED_FENCE 1
 #endif
-#include "upx_kernels.h"
+#if !defined(UPX_EXPERIMENTS)
+#error "experiment kernels: build with -DUPX_EXPERIMENTS (__graft_entry__.build_hip(extra_flags=[\"-DUPX_EXPERIMENTS\"], lib=...)); not part of libupmix_hip.so"
+#endif
+#include "../upx_kernels.h"
 
 namespace upxk {
 

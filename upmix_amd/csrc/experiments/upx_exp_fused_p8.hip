@@ -1,5 +1,8 @@
-// upx_reg_fused_p8.hip - fused streaming kernels with 8 points per lane, 4 waves per SIMD (UPX_KERNEL_VARIANT; upx_kernels.h).
-#include "upx_kernels.h"
+// experiments/upx_exp_fused_p8.hip - fused streaming kernels with 8 points per lane, 4 waves per SIMD (UPX_KERNEL_VARIANT; upx_kernels.h).
+#if !defined(UPX_EXPERIMENTS)
+#error "experiment kernels: build with -DUPX_EXPERIMENTS (__graft_entry__.build_hip(extra_flags=[\"-DUPX_EXPERIMENTS\"], lib=...)); not part of libupmix_hip.so"
+#endif
+#include "../upx_kernels.h"
 
 namespace upxk {
 const KernelEntry* find_kernel_p8(int log2n, int k) {

@@ -1,5 +1,8 @@
-// upx_reg_fused_plain.hip - fused streaming kernels with the plain Stockham schedule for every size (UPX_KERNEL_VARIANT; upx_kernels.h).
-#include "upx_kernels.h"
+// experiments/upx_exp_fused_plain.hip - fused streaming kernels with the plain Stockham schedule for every size (UPX_KERNEL_VARIANT; upx_kernels.h).
+#if !defined(UPX_EXPERIMENTS)
+#error "experiment kernels: build with -DUPX_EXPERIMENTS (__graft_entry__.build_hip(extra_flags=[\"-DUPX_EXPERIMENTS\"], lib=...)); not part of libupmix_hip.so"
+#endif
+#include "../upx_kernels.h"
 
 namespace upxk {
 const KernelEntry* find_kernel_plain(int log2n, int k) {

@@ -825,14 +825,14 @@ struct BandArgs {
     // ran at four speeds (233 / 283 / 283 / 298 us for the same work) and take the top priority in turn, a frame pair each.
     int prio_split;
     int prio_young;        // prio_split > 0: frame pairs out of 4 in which the younger half leads (3 balances; 2 = even turns)
-    // Stream seams inside the launch (round 5; upxk::seam_epilogue): pair_cnt != nullptr: the workgroups w and w + 1 each
-    // add 1 to pair_cnt[w] when they are done; whoever finds the count odd came SECOND - both tails and both heads exist -
-    // and adds the tail of w's last stream onto the first blocks of w + 1's first stream (stream_seam_add, addition for
-    // addition what upx_stream_seam_add_kernel does in a launch of its own).  Nobody waits for anybody: no spinning, no
-    // assumption about which workgroups are resident.  The counts only ever grow (two per pair and launch), so they need no
-    // reset between launches.
+#if defined(UPX_EXPERIMENTS)
+    // EXPERIMENT builds only (-DUPX_EXPERIMENTS; rejected in round 5, docs/LOG.md): stream seams inside the launch
+    // (upxk::seam_epilogue).  pair_cnt != nullptr: the workgroups w and w + 1 each add 1 to pair_cnt[w] when they are done;
+    // whoever finds the count odd came SECOND and adds the tail of w's last stream onto the first blocks of w + 1's first
+    // stream.  The product library has neither the fields nor the epilogue: its kernels take exactly the arguments above.
     int* pair_cnt;
     int n_streams;         // streams of the launch (stream_seam_add's guard)
+#endif
 };
 
 constexpr float kEps = 1e-12f;   // center_extraction.py:36

@@ -65,6 +65,7 @@ struct DevExec {
     }
 };
 
+#if defined(UPX_EXPERIMENTS)
 // Stream seams inside the launch (BandArgs::pair_cnt).  Runs after band_program: every stream of the workgroup has written
 // its hops and its tail.  Seams between two streams of ONE workgroup are added right away; for the seam to either
 // neighbour workgroup, the two workgroups count up pair_cnt[w] and the second arriver adds.  Memory: the counter update is
@@ -94,6 +95,7 @@ __device__ __forceinline__ void seam_epilogue(const upx::BandArgs& a, int wg, in
         if (s1) add(wg * C::G + C::G - 1);
     }
 }
+#endif
 
 // WPE = waves per SIMD the register allocator must leave room for (2 -> 256 VGPRs, 3 -> 168).
 // MERGED = false: the launch carries one band (one gain slot per bin): the flavour single bands get.
@@ -103,13 +105,15 @@ __global__ __launch_bounds__(C::WG, WPE) void upx_band_kernel(upx::BandArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using Ex = DevExec<C::WAVE_SYNC || C::WIDE, C::P>;
     Ex ex;
-    // the interior flavour (two more instantiations of the program) for the kernels plans select by default; the
-    // 8-points-per-lane and plain-schedule alternates (UPX_KERNEL_VARIANT) keep the one general body
+    // the interior flavour (two more instantiations of the program) for the kernels plans select; the 8-points-per-lane
+    // and plain-schedule alternates of experiment builds (csrc/experiments/) keep the one general body
     if constexpr (C::P == 16 && (C::WIDE || C::LOG2N <= 11))
         upx::band_program_auto<C, Ex, MERGED, LV>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
     else
         upx::band_program<C, Ex, MERGED>(ex, a, reinterpret_cast<upx::cf*>(smem), (int)blockIdx.x);
+#if defined(UPX_EXPERIMENTS)
     if (a.pair_cnt) seam_epilogue<C>(a, (int)blockIdx.x, (int)gridDim.x);
+#endif
 }
 
 // ---- unfused path: STFT sizes 16384..65536 and arbitrary hops (upx_big.h) ---------------------
@@ -310,12 +314,15 @@ struct Entry {
 //   variant 0: 16 points per lane, register budget for 2 waves/SIMD (256 VGPRs); N = 4096 / 8192 as wide streams
 //   variant 10: variant 0 for launches that carry a single band; 100 + 10 S0 + S1: ... specialised for the live
 //               own-bin slots [S0, S1) (upx::Live)
+const KernelEntry* find_kernel_default(int log2n, int k, int variant);   // variants 0, 10, 100+
+#if defined(UPX_EXPERIMENTS)
+// experiment builds only (csrc/experiments/upx_exp_*.hip; none of them is in libupmix_hip.so):
 //   variant 1:  8 points per lane, register budget for 4 waves/SIMD (128 VGPRs)
 //   variant 2: 16 points per lane, plain Stockham schedule for every size
-const KernelEntry* find_kernel_default(int log2n, int k, int variant);   // variants 0, 10, 100+
-const KernelEntry* find_kernel_dual(int log2n, int live_s1);             // experiment: two stream sets per wave (upx_reg_fused_dual.hip)
+const KernelEntry* find_kernel_dual(int log2n, int live_s1);             // two stream sets per wave
 const KernelEntry* find_kernel_p8(int log2n, int k);                     // variant 1
 const KernelEntry* find_kernel_plain(int log2n, int k);                  // variant 2
+#endif
 // (log2 P, residues per workgroup, K) -> kernels of the band-limited path
 const ZoomEntry* find_zoom_p256(int rg, int k);
 const ZoomEntry* find_zoom_p512(int rg, int k);

@@ -293,11 +293,23 @@ constexpr int kMidEvents = 15;           // up to 8 launch pairs of the band-lim
 constexpr int kTimingSlots = 64;          // recent upx_process_device calls whose per-band events are kept
 constexpr int kMaxFramesPerSample = 64;   // unfused path: ceil(N / hop) frames overlap one sample
 
-// (log2 N, K, variant) -> fused kernel; the tables live in upx_reg_fused*.hip.  UPX_KERNEL_VARIANT selects the variant;
-// the default is set in default_variant().
+// Tuning and test knobs.  The library reads UPX_* variables at plan creation ONLY when the process opts in with
+// UPX_TUNING=1 (the test suite, scripts/, the A/B harness); without it the environment cannot change which kernels a plan
+// selects, how a launch is cut into streams or where chunk seams fall - a caller's results do not depend on what a shell
+// happened to export (round-5 review).  Operational settings stay unconditional: UPX_COMM_TIMEOUT / UPX_RDZV_TIMEOUT
+// (upx_comm_create), and on the Python side UPX_PINNED_POOL_MB and the UPX_RDZV_* rendezvous variables.
+const char* knob(const char* name) {
+    const char* on = std::getenv("UPX_TUNING");
+    if (!on || std::strcmp(on, "1") != 0) return nullptr;
+    return std::getenv(name);
+}
+
+// (log2 N, K, variant) -> fused kernel; the tables live in upx_reg_fused*.hip.
 const KernelEntry* find_kernel(int log2n, int k, int variant) {
+#if defined(UPX_EXPERIMENTS)
     if (variant == 1) return find_kernel_p8(log2n, k);
     if (variant == 2) return find_kernel_plain(log2n, k);
+#endif
     const KernelEntry* e = find_kernel_default(log2n, k, variant);
     if (!e && variant >= 100) return nullptr;   // live-slot flavours: the caller tries the next wider one
     if (!e && variant != 0) e = find_kernel_default(log2n, k, 0);
@@ -307,9 +319,15 @@ const ZoomEntry* find_zoom(int log2p, int rg, int k) {
     return log2p == 8 ? find_zoom_p256(rg, k) : log2p == 9 ? find_zoom_p512(rg, k) : log2p == 10 ? find_zoom_p1024(rg, k) : nullptr;
 }
 
+// 0 in the product library; experiment builds (-DUPX_EXPERIMENTS) take UPX_KERNEL_VARIANT = 1 (8 points per lane) / 2 (plain
+// Stockham schedule) from csrc/experiments/
 int default_variant() {
-    const char* v = std::getenv("UPX_KERNEL_VARIANT");
+#if defined(UPX_EXPERIMENTS)
+    const char* v = knob("UPX_KERNEL_VARIANT");
     return v ? std::atoi(v) : 0;
+#else
+    return 0;
+#endif
 }
 
 int ilog2_exact(int v) {
@@ -349,6 +367,7 @@ struct BandState {
     int group_size = 1;                 // leader: bands merged into its launch; merged members: 0
     int n_gain = 1;                     // gain slots per bin (merged bands overlap at crossovers)
     int last_wg = 0, last_f = 0;
+    int timed_wg = 0;                   // last_wg of the last TIMED call (ev0 / ev1 belong to it)
     // launch geometry of the last call against the chip: workgroups of the (first) launch of the main kernel / of the
     // band-limited analysis and the workgroup slots the chip holds of them at once (upx_plan_band_fill)
     int fill_wg = 0, fill_slots = 0, fill_wg_a = 0, fill_slots_a = 0;
@@ -385,11 +404,15 @@ struct upx_plan {
     int knob_zoom_edge_percent = 76;        // UPX_ZOOM_EDGE_PERCENT: length of the first / last synthesis stream of a signal (100 = like the others)
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
     int knob_seam_vec = 1;                  // UPX_SEAM_VEC: stream-seam passes with 16-byte accesses where alignment allows (0: scalar passes)
-    int knob_first_band = -1;               // UPX_FIRST_BAND: launch this band's group first (-1: list order, the reference's sum order)
-    int knob_seam_inkernel = 0;             // UPX_SEAM_INKERNEL (experiment, rejected: profiles/r05_seam_inkernel_ab.txt): stream seams of fused launches inside the launch (0 never, 1 always, 2 when the launch does not fill the chip)
-    int* d_pair_cnt = nullptr;              // counters of seam_epilogue, one per neighbouring workgroup pair (only ever grow)
+#if defined(UPX_EXPERIMENTS)
+    // experiment builds only (round 4 / 5 A/Bs, all rejected: docs/LOG.md).  The product library launches the groups in list
+    // order - the reference's float32 band sum ((0 + b0) + b1) + ... (center_extraction.py:508-511) - and nothing can change that.
+    int knob_first_band = -1;               // UPX_FIRST_BAND: launch this band's group first
+    int knob_seam_inkernel = 0;             // UPX_SEAM_INKERNEL: stream seams of fused launches inside the launch (0 never, 1 always, 2 when the launch does not fill the chip)
+    int* d_pair_cnt = nullptr;              // counters of seam_epilogue, one per neighbouring workgroup pair; allocated when the knob is on
     int pair_cnt_n = 1 << 16;
-    int knob_band_rotate = 0;               // UPX_BAND_ROTATE (experiment): the launch groups start this many groups into the list (another sum association)
+    int knob_band_rotate = 0;               // UPX_BAND_ROTATE: the launch groups start this many groups into the list (another sum association)
+#endif
     int knob_min_stream_frames = 4;         // UPX_MIN_STREAM_FRAMES: shortest stream of a fused launch that does not fill the chip (>= K, even)
     int knob_prio_young = 3;                // UPX_PRIO_YOUNG: frame pairs of 4 in which the younger half of a launch leads (0 = off)
     float* d_seam = nullptr;        // stream tails of the fused kernel: [streams][3][(K-1) hop]
@@ -447,7 +470,8 @@ struct upx_comm {
     int rank = 0, n_ranks = 1;
     float* d_seam = nullptr;
     long long seam_floats = 0;
-    hipEvent_t ev_done = nullptr;   // behind the last seam exchange on the plan's stream (upx_comm_wait)
+    hipEvent_t ev_start = nullptr;  // in front of the last seam exchange's all-reduce on the plan's stream ...
+    hipEvent_t ev_done = nullptr;   // ... and behind the exchange (upx_comm_wait: the peers' time limit starts at ev_start)
     bool pending = false;           // an exchange has been queued and not yet waited for
     bool aborted = false;           // ncclCommAbort has run: the communicator is gone
     double timeout_s = 600.0;       // UPX_COMM_TIMEOUT, else UPX_RDZV_TIMEOUT, else 600 s
@@ -580,10 +604,15 @@ int upx_supported(int32_t block_size, int32_t hop) {
     return (block_size + hop - 1) / hop <= kMaxFramesPerSample ? 1 : 0;
 }
 
-int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* block_size, const int32_t* hop,
-                    const float* w_analysis, const float* w_synthesis, const float* gain) {
-    if (!out || n_bands < 1 || !block_size || !hop || !w_analysis || !w_synthesis || !gain)
-        return fail(UPX_ERR_INVALID, "upx_plan_create: NULL argument or n_bands < 1");
+// ---------------------------------------------------------------------------
+// upx_plan_create = selection (host arithmetic: launch groups, kernel family and flavour per group, per-bin gain tables;
+// plan_select - no device is touched, upx_plan_kernel_names runs it alone) + upload (device tables and buffers; plan_upload)
+// ---------------------------------------------------------------------------
+namespace {
+int check_bands(const char* who, int n_bands, const int32_t* block_size, const int32_t* hop, const float* w_analysis,
+                const float* w_synthesis, const float* gain) {
+    if (n_bands < 1 || !block_size || !hop || !w_analysis || !w_synthesis || !gain)
+        return fail(UPX_ERR_INVALID, "%s: NULL argument or n_bands < 1", who);
     for (int b = 0; b < n_bands; ++b) {
         if (hop[b] < 1) return fail(UPX_ERR_INVALID, "Overlap too large; hop size < 1 is not allowed.");
         if (!upx_supported(block_size[b], hop[b]))
@@ -592,48 +621,43 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                         "(power-of-two sizes 64..65536, at most 64 frames overlapping a sample)",
                         b, block_size[b], hop[b]);
     }
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(UPX_ERR_NO_DEVICE, "no HIP device visible");
-    if (device < 0 || device >= n_dev) return fail(UPX_ERR_INVALID, "device %d out of range (0..%d)", device, n_dev - 1);
-    HIP_TRY(hipSetDevice(device));
-    // every early return below releases what has been created so far (stream, events, device memory)
-    struct Guard {
-        upx_plan* p;
-        ~Guard() { if (p) upx_plan_destroy(p); }
-    } guard{new upx_plan()};
-    upx_plan* p = guard.p;
-    p->device = device;
-    if (const char* e = std::getenv("UPX_ZOOM_SCRATCH_MB")) p->knob_zoom_scratch_mb = std::atoll(e);
-    if (const char* e = std::getenv("UPX_ZOOM_FILL")) p->knob_zoom_fill = std::atof(e);
-    if (const char* e = std::getenv("UPX_ZOOM_F")) p->knob_zoom_f = std::atoll(e);
-    if (const char* e = std::getenv("UPX_STREAM_CHUNK")) p->knob_stream_chunk = std::atoll(e);
-    if (const char* e = std::getenv("UPX_EDGE_PERCENT")) p->knob_edge_percent = std::atoi(e);
-    if (const char* e = std::getenv("UPX_PRIO_YOUNG")) p->knob_prio_young = std::atoi(e);
-    if (const char* e = std::getenv("UPX_MIN_STREAM_FRAMES")) p->knob_min_stream_frames = std::atoi(e);
-    if (const char* e = std::getenv("UPX_WAV_CHUNK")) p->knob_wav_chunk = std::atoll(e);
-    if (const char* e = std::getenv("UPX_FIRST_BAND")) p->knob_first_band = std::atoi(e);
-    if (const char* e = std::getenv("UPX_SEAM_VEC")) p->knob_seam_vec = std::atoi(e);
-    if (const char* e = std::getenv("UPX_WAV_UNIFORM")) p->knob_wav_uniform = std::atoi(e);
-    if (const char* e = std::getenv("UPX_WAV_KERNEL_RATE")) p->knob_wav_kernel_rate = std::atof(e);
-    if (const char* e = std::getenv("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
-    if (const char* e = std::getenv("UPX_ZOOM_C_COST")) p->knob_zoom_c_cost = std::atof(e);
-    if (const char* e = std::getenv("UPX_ZOOM_EDGE_PERCENT")) p->knob_zoom_edge_percent = std::atoi(e);
-    if (const char* e = std::getenv("UPX_ZOOM_A_AGE")) p->knob_zoom_a_age = std::atoi(e);
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-        p->n_cu = prop.multiProcessorCount;
-    // UPX_N_CU (experiment): the launch geometry is cut for this many compute units, e.g. half the chip for each of two
-    // plans whose launches are meant to be resident side by side (scripts/r5_two_tiles.py)
-    if (const char* e = std::getenv("UPX_N_CU"))
+    return UPX_OK;
+}
+
+void read_knobs(upx_plan* p) {
+    if (const char* e = knob("UPX_ZOOM_SCRATCH_MB")) p->knob_zoom_scratch_mb = std::atoll(e);
+    if (const char* e = knob("UPX_ZOOM_FILL")) p->knob_zoom_fill = std::atof(e);
+    if (const char* e = knob("UPX_ZOOM_F")) p->knob_zoom_f = std::atoll(e);
+    if (const char* e = knob("UPX_STREAM_CHUNK")) p->knob_stream_chunk = std::atoll(e);
+    if (const char* e = knob("UPX_EDGE_PERCENT")) p->knob_edge_percent = std::atoi(e);
+    if (const char* e = knob("UPX_PRIO_YOUNG")) p->knob_prio_young = std::atoi(e);
+    if (const char* e = knob("UPX_MIN_STREAM_FRAMES")) p->knob_min_stream_frames = std::atoi(e);
+    if (const char* e = knob("UPX_WAV_CHUNK")) p->knob_wav_chunk = std::atoll(e);
+    if (const char* e = knob("UPX_SEAM_VEC")) p->knob_seam_vec = std::atoi(e);
+    if (const char* e = knob("UPX_WAV_UNIFORM")) p->knob_wav_uniform = std::atoi(e);
+    if (const char* e = knob("UPX_WAV_KERNEL_RATE")) p->knob_wav_kernel_rate = std::atof(e);
+    if (const char* e = knob("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
+    if (const char* e = knob("UPX_ZOOM_C_COST")) p->knob_zoom_c_cost = std::atof(e);
+    if (const char* e = knob("UPX_ZOOM_EDGE_PERCENT")) p->knob_zoom_edge_percent = std::atoi(e);
+    if (const char* e = knob("UPX_ZOOM_A_AGE")) p->knob_zoom_a_age = std::atoi(e);
+#if defined(UPX_EXPERIMENTS)
+    // UPX_N_CU: the launch geometry is cut for this many compute units, e.g. half the chip for each of two plans whose
+    // launches are meant to be resident side by side (scripts/r5_two_tiles.py)
+    if (const char* e = knob("UPX_N_CU"))
         if (std::atoi(e) >= 8) p->n_cu = std::atoi(e);
-    if (const char* e = std::getenv("UPX_BAND_ROTATE")) p->knob_band_rotate = std::atoi(e);
-    if (const char* e = std::getenv("UPX_SEAM_INKERNEL")) p->knob_seam_inkernel = std::atoi(e);
-    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(&p->d_scalar, sizeof(unsigned int)));
-    HIP_TRY(hipMalloc(&p->d_pair_cnt, (size_t)p->pair_cnt_n * sizeof(int)));
-    HIP_TRY(hipMemset(p->d_pair_cnt, 0, (size_t)p->pair_cnt_n * sizeof(int)));
+    if (const char* e = knob("UPX_FIRST_BAND")) p->knob_first_band = std::atoi(e);
+    if (const char* e = knob("UPX_BAND_ROTATE")) p->knob_band_rotate = std::atoi(e);
+    if (const char* e = knob("UPX_SEAM_INKERNEL")) p->knob_seam_inkernel = std::atoi(e);
+#endif
+}
+
+// Selection: p->bands gets geometry, launch groups, pass band, kernel family and flavour; gain_tables[b] the per-bin gain
+// list of the launch band b leads, in the order its kernel reads it.  Host arithmetic only.
+int plan_select(upx_plan* p, int n_bands, const int32_t* block_size, const int32_t* hop, const float* w_analysis,
+                const float* w_synthesis, const float* gain, std::vector<size_t>& band_win_off,
+                std::vector<std::vector<float>>& gain_tables) {
     p->bands.resize(n_bands);
-    std::vector<size_t> band_win_off, band_gain_off;
+    std::vector<size_t> band_gain_off;
     // pass 1: geometry, merged groups, pass band
     {
         size_t off_w = 0, off_g = 0;
@@ -647,7 +671,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             // Merge with the previous band when it has the same STFT size, hop and (bit-identical) windows:
             // the transforms are then the same linear operators and only gain -> mask runs per band.
             s.group_leader = b;
-            if (b > 0 && !std::getenv("UPX_NO_BAND_MERGE")) {
+            if (b > 0 && !knob("UPX_NO_BAND_MERGE")) {
                 const BandState& q = p->bands[b - 1];
                 if (q.n == s.n && q.hop == s.hop &&
                     !std::memcmp(w_analysis + off_w, w_analysis + off_w - s.n, s.n * sizeof(float)) &&
@@ -674,11 +698,11 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     //     1024 with D = N / P >= 8: the reference's planner makes every band with a large STFT such a band;
     //   fused streaming kernel (upx_core.h): the same hops, N <= 8192, any pass band;
     //   unfused pipeline (upx_big.h): everything else.
-    const bool force_unfused = std::getenv("UPX_FORCE_UNFUSED") != nullptr;
+    const bool force_unfused = knob("UPX_FORCE_UNFUSED") != nullptr;
     // UPX_ZOOM = smallest decimation D = N / P (>= 8) for which the band-limited path is taken (0: never).  Measured on
     // the MI355X: from D = 8 on it beats the fused kernel (N = 4096: 0.46 vs 0.54 ms); at D = 4 the fused
     // kernel's single launch wins.
-    const char* zoom_env = std::getenv("UPX_ZOOM");
+    const char* zoom_env = knob("UPX_ZOOM");
     const int zoom_min_d = zoom_env ? std::atoi(zoom_env) : 8;
     for (int b = 0; b < n_bands; ++b) {
         BandState& s = p->bands[b];
@@ -699,7 +723,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                     // groups per frame) measured 0.664 -> 0.593 ms on C4's main group (N = 8192, P = 512) and -5 % on the
                     // default plan's 65 536 / 16 384 bands; at P = 256 sixteen stay (+3 % with eight).  UPX_ZOOM_A_RG overrides.
                     s.zoom_a = s.zoom;
-                    const char* e = std::getenv("UPX_ZOOM_A_RG");
+                    const char* e = knob("UPX_ZOOM_A_RG");
                     const int rg_a = e ? std::atoi(e) : (zp >= 512 ? 8 : s.zoom->rg);
                     if (rg_a != s.zoom->rg) {
                         const ZoomEntry* alt = find_zoom(ilog2_exact(zp), rg_a, s.k);
@@ -710,17 +734,84 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         }
         if (!s.zoom && std_hop && !force_unfused) s.kern = find_kernel(s.log2n, s.n / s.hop, default_variant());
         if (!s.zoom && !s.kern) s.big = find_big(s.log2n);
-        if (s.zoom && s.zoom_a != s.zoom)
-            if (int e = s.zoom_a->prepare())
-                return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
-        if (int e = s.zoom ? s.zoom->prepare() : (s.kern ? s.kern->prepare() : s.big->prepare()))
-            return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
+    }
+    // pass 3: per-bin gain lists of the (possibly merged) launch: gain[q][k] = q-th non-zero half-gain of bin k, band
+    // order - and, from them, the flavour of a fused launch that carries one band
+    gain_tables.assign(n_bands, {});
+    for (int b = 0; b < n_bands; ++b) {
+        BandState& s = p->bands[b];
+        if (s.group_size == 0) continue;
+        const int nb = s.n / 2 + 1;
+        std::vector<int> count(nb, 0);
+        int slots = 1;
+        for (int m = b; m < b + s.group_size; ++m)
+            for (int k = 0; k < nb; ++k)
+                if (gain[band_gain_off[m] + k] != 0.f && ++count[k] > slots) slots = count[k];
+        std::vector<float>& table = gain_tables[b];
+        table.assign((size_t)slots * nb, 0.f);
+        std::fill(count.begin(), count.end(), 0);
+        for (int m = b; m < b + s.group_size; ++m)
+            for (int k = 0; k < nb; ++k) {
+                const float g = gain[band_gain_off[m] + k];
+                if (g != 0.f) table[(size_t)count[k]++ * nb + k] = 0.5f * g;
+            }
+        if (!s.zoom) {
+            // rows in the order the kernel's threads read them (natural for plain streams, whole-frame rows and
+            // the band-limited path)
+            int (*order)(int) = s.kern ? s.kern->gain_bin : s.big->gain_bin;
+            std::vector<float> natural(table);
+            for (int q = 0; q < slots; ++q)
+                for (int i = 0; i < nb; ++i) table[(size_t)q * nb + i] = natural[(size_t)q * nb + order(i)];
+        }
+        s.n_gain = slots;
+        if (s.kern && slots == 1 && s.log2n != 12 && default_variant() == 0 && !knob("UPX_NO_SINGLE_FLAVOUR")) {
+            // one gain slot per bin: the flavour without the second slot's registers (same twiddle / gain layout).
+            // Measured (MI355X, C4 plan): N = 2048 1.52 -> 1.43 ms (its ten spills are gone), N = 512 1.43 -> 1.39;
+            // N = 4096 loses 3 % (its few spills sit on the signal-edge path only), so it keeps the general flavour.
+            const KernelEntry* one = find_kernel(s.log2n, s.n / s.hop, 10);
+            if (one && one->layout == s.kern->layout) {
+                // ... and, where one is built, the flavour specialised for the own-bin slots that carry gain: slot s of
+                // a lane holds bin lane + s lanes (s < 8); the smallest instantiated range [S0, S1) that covers them,
+                // S1 = 8 whenever the Nyquist bin carries gain
+                if (!knob("UPX_NO_LIVE_FLAVOUR") && s.k == 4) {
+                    int lo = 8, hi = 0;
+                    for (int sl = 0; sl < 8; ++sl)
+                        for (int i = sl * one->lanes; i < (sl + 1) * one->lanes; ++i)
+                            if (table[(size_t)i] != 0.f) { lo = sl < lo ? sl : lo; hi = sl + 1; break; }
+                    if (table[(size_t)nb - 1] != 0.f) hi = 8;
+                    const KernelEntry* live = nullptr;
+                    for (int b1 = hi; b1 <= 8 && !live && lo < hi; ++b1)
+                        for (int a0 = lo > 1 ? 1 : lo; a0 >= 0 && !live; --a0)
+                            if (a0 > 0 || b1 < 8) live = find_kernel(s.log2n, 4, 100 + 10 * a0 + b1);
+                    if (live && live->layout == s.kern->layout) one = live;
+#if defined(UPX_EXPERIMENTS)
+                    // UPX_DUAL = 1: two stream sets per wave, one wave per SIMD (experiments/upx_exp_fused_dual.hip);
+                    // = 2: the N = 256 launch only, = 3: the N = 1024 launch only
+                    if (const char* e = knob("UPX_DUAL")) {
+                        const int mode = std::atoi(e);
+                        const bool want = mode == 1 || (mode == 2 && s.log2n == 8) || (mode == 3 && s.log2n == 10);
+                        const KernelEntry* dual = want ? find_kernel_dual(s.log2n, live == one ? hi : 0) : nullptr;
+                        if (want && !dual) dual = find_kernel_dual(s.log2n, 0);
+                        if (dual && dual->layout == s.kern->layout) one = dual;
+                    }
+#endif
+                }
+                s.kern = one;
+            }
+        }
         for (int m = b + 1; m < b + s.group_size; ++m) {   // members: only for reporting
             p->bands[m].zoom = s.zoom; p->bands[m].zoom_a = s.zoom_a; p->bands[m].kern = s.kern; p->bands[m].big = s.big;
             p->bands[m].zoom_p = s.zoom_p; p->bands[m].zoom_d = s.zoom_d;
         }
     }
-    // pass 3: device tables
+    return UPX_OK;
+}
+
+// Upload: what the selected kernels read on the device - windows, twiddles, ramp seeds, gain tables - and the plan's
+// buffers (timing events, scratch of the unfused and band-limited paths, stream seam buffer)
+int plan_upload(upx_plan* p, const float* w_analysis, const float* w_synthesis, const std::vector<size_t>& band_win_off,
+                const std::vector<std::vector<float>>& gain_tables) {
+    const int n_bands = (int)p->bands.size();
     for (int b = 0; b < n_bands; ++b) {
         BandState& s = p->bands[b];
         const size_t off_w = band_win_off[b];
@@ -734,6 +825,12 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         s.ev0 = s.ring0[0];
         s.ev1 = s.ring1[0];
         if (s.group_size == 0) continue;   // carried by its group leader's launch
+        // the dynamic LDS of the group's kernels
+        if (s.zoom && s.zoom_a != s.zoom)
+            if (int e = s.zoom_a->prepare())
+                return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
+        if (int e = s.zoom ? s.zoom->prepare() : (s.kern ? s.kern->prepare() : s.big->prepare()))
+            return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
         if (s.zoom) {
             s.ring_mid.assign((size_t)kTimingSlots * kMidEvents, nullptr);
             s.ring_mid_n.assign(kTimingSlots, 0);
@@ -774,7 +871,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             // frames per chunk: 2^24 complex per scratch buffer (128 MB; z + y + yc = 320 MB).  Measured on the
             // default plan: 2^21 10.2 ms, 2^22 7.9, 2^23 7.0, 2^24 6.7, 2^25 8.3 - below, the 7 launches per chunk
             // (10-19 us each) are too short; above, the scratch falls out of the Infinity Cache altogether.
-            const char* cl = std::getenv("UPX_BIG_CHUNK_LOG2");
+            const char* cl = knob("UPX_BIG_CHUNK_LOG2");
             s.chunk_frames = (1 << (cl ? std::atoi(cl) : 24)) / s.n;
             if (s.chunk_frames < 2 * s.k + 4) s.chunk_frames = 2 * s.k + 4;
             s.chunk_frames += s.chunk_frames & 1;
@@ -785,64 +882,7 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
             const size_t need = (size_t)s.chunk_frames * s.n * 5 / 2;   // z + y + yc/2
             if (need > p->scratch_cf) p->scratch_cf = need;
         }
-        // per-bin gain lists of the (possibly merged) launch: gain[q][k] = q-th non-zero half-gain of bin k, band order
-        const int nb = s.n / 2 + 1;
-        std::vector<int> count(nb, 0);
-        int slots = 1;
-        for (int m = b; m < b + s.group_size; ++m)
-            for (int k = 0; k < nb; ++k)
-                if (gain[band_gain_off[m] + k] != 0.f && ++count[k] > slots) slots = count[k];
-        std::vector<float> table((size_t)slots * nb, 0.f);
-        std::fill(count.begin(), count.end(), 0);
-        for (int m = b; m < b + s.group_size; ++m)
-            for (int k = 0; k < nb; ++k) {
-                const float g = gain[band_gain_off[m] + k];
-                if (g != 0.f) table[(size_t)count[k]++ * nb + k] = 0.5f * g;
-            }
-        if (!s.zoom) {
-            // rows in the order the kernel's threads read them (natural for plain streams, whole-frame rows and
-            // the band-limited path)
-            int (*order)(int) = s.kern ? s.kern->gain_bin : s.big->gain_bin;
-            std::vector<float> natural(table);
-            for (int q = 0; q < slots; ++q)
-                for (int i = 0; i < nb; ++i) table[(size_t)q * nb + i] = natural[(size_t)q * nb + order(i)];
-        }
-        s.n_gain = slots;
-        if (s.kern && slots == 1 && s.log2n != 12 && default_variant() == 0 && !std::getenv("UPX_NO_SINGLE_FLAVOUR")) {
-            // one gain slot per bin: the flavour without the second slot's registers (same twiddle / gain layout).
-            // Measured (MI355X, C4 plan): N = 2048 1.52 -> 1.43 ms (its ten spills are gone), N = 512 1.43 -> 1.39;
-            // N = 4096 loses 3 % (its few spills sit on the signal-edge path only), so it keeps the general flavour.
-            const KernelEntry* one = find_kernel(s.log2n, s.n / s.hop, 10);
-            if (one && one->layout == s.kern->layout) {
-                // ... and, where one is built, the flavour specialised for the own-bin slots that carry gain: slot s of
-                // a lane holds bin lane + s lanes (s < 8); the smallest instantiated range [S0, S1) that covers them,
-                // S1 = 8 whenever the Nyquist bin carries gain
-                if (!std::getenv("UPX_NO_LIVE_FLAVOUR") && s.k == 4) {
-                    int lo = 8, hi = 0;
-                    for (int sl = 0; sl < 8; ++sl)
-                        for (int i = sl * one->lanes; i < (sl + 1) * one->lanes; ++i)
-                            if (table[(size_t)i] != 0.f) { lo = sl < lo ? sl : lo; hi = sl + 1; break; }
-                    if (table[(size_t)nb - 1] != 0.f) hi = 8;
-                    const KernelEntry* live = nullptr;
-                    for (int b1 = hi; b1 <= 8 && !live && lo < hi; ++b1)
-                        for (int a0 = lo > 1 ? 1 : lo; a0 >= 0 && !live; --a0)
-                            if (a0 > 0 || b1 < 8) live = find_kernel(s.log2n, 4, 100 + 10 * a0 + b1);
-                    if (live && live->layout == s.kern->layout) one = live;
-                    // UPX_DUAL = 1 (experiment): two stream sets per wave, one wave per SIMD (upx_reg_fused_dual.hip);
-                    // = 2: the N = 256 launch only, = 3: the N = 1024 launch only
-                    if (const char* e = std::getenv("UPX_DUAL")) {
-                        const int mode = std::atoi(e);
-                        const bool want = mode == 1 || (mode == 2 && s.log2n == 8) || (mode == 3 && s.log2n == 10);
-                        const KernelEntry* dual = want ? find_kernel_dual(s.log2n, live == one ? hi : 0) : nullptr;
-                        if (want && !dual) dual = find_kernel_dual(s.log2n, 0);
-                        if (dual && dual->layout == s.kern->layout) one = dual;
-                    }
-                }
-                if (int e = one->prepare())
-                    return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
-                s.kern = one;
-            }
-        }
+        const std::vector<float>& table = gain_tables[b];
         HIP_TRY(hipMalloc(&s.d_gain, table.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(s.d_gain, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
     }
@@ -857,8 +897,78 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
         if (need > p->seam_floats) p->seam_floats = need;
     }
     if (p->seam_floats) HIP_TRY(hipMalloc(&p->d_seam, p->seam_floats * sizeof(float)));
+    return UPX_OK;
+}
+
+// "analysis|synthesis" for a band-limited group, the one kernel otherwise
+void group_kernel_names(const BandState& s, std::string& out) {
+    if (s.zoom) {
+        out += std::string(s.zoom_a->name_analysis) + "|" + s.zoom->name_synthesis;
+    } else if (s.kern) {
+        out += s.kern->name;
+    } else {
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "upx_big pipeline, STFT %d (upx_big.h)", s.n);
+        out += buf;
+    }
+}
+}   // namespace
+
+int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* block_size, const int32_t* hop,
+                    const float* w_analysis, const float* w_synthesis, const float* gain) {
+    if (!out) return fail(UPX_ERR_INVALID, "upx_plan_create: NULL argument or n_bands < 1");
+    if (int rc = check_bands("upx_plan_create", n_bands, block_size, hop, w_analysis, w_synthesis, gain)) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(UPX_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n_dev) return fail(UPX_ERR_INVALID, "device %d out of range (0..%d)", device, n_dev - 1);
+    HIP_TRY(hipSetDevice(device));
+    // every early return below releases what has been created so far (stream, events, device memory)
+    struct Guard {
+        upx_plan* p;
+        ~Guard() { if (p) upx_plan_destroy(p); }
+    } guard{new upx_plan()};
+    upx_plan* p = guard.p;
+    p->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        p->n_cu = prop.multiProcessorCount;
+    read_knobs(p);
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&p->d_scalar, sizeof(unsigned int)));
+#if defined(UPX_EXPERIMENTS)
+    if (p->knob_seam_inkernel != 0) {
+        HIP_TRY(hipMalloc(&p->d_pair_cnt, (size_t)p->pair_cnt_n * sizeof(int)));
+        HIP_TRY(hipMemset(p->d_pair_cnt, 0, (size_t)p->pair_cnt_n * sizeof(int)));
+    }
+#endif
+    std::vector<size_t> band_win_off;
+    std::vector<std::vector<float>> gain_tables;
+    if (int rc = plan_select(p, n_bands, block_size, hop, w_analysis, w_synthesis, gain, band_win_off, gain_tables)) return rc;
+    if (int rc = plan_upload(p, w_analysis, w_synthesis, band_win_off, gain_tables)) return rc;
     guard.p = nullptr;
     *out = p;
+    return UPX_OK;
+}
+
+// The selection alone, without a device: for every band the kernel(s) of the launch that carries it - "analysis|synthesis"
+// for a band-limited group - one line per band, in `names` (NUL-terminated; UPX_ERR_INVALID when n is too small).  What
+// upx_plan_create would select in THIS process (the same UPX_TUNING gate); CPU tests pin the selection with it.
+int upx_plan_kernel_names(int n_bands, const int32_t* block_size, const int32_t* hop, const float* w_analysis,
+                          const float* w_synthesis, const float* gain, char* names, size_t n) {
+    if (!names || n == 0) return fail(UPX_ERR_INVALID, "upx_plan_kernel_names: NULL argument");
+    if (int rc = check_bands("upx_plan_kernel_names", n_bands, block_size, hop, w_analysis, w_synthesis, gain)) return rc;
+    upx_plan plan;          // never reaches the device: no stream, no buffers
+    read_knobs(&plan);
+    std::vector<size_t> band_win_off;
+    std::vector<std::vector<float>> gain_tables;
+    if (int rc = plan_select(&plan, n_bands, block_size, hop, w_analysis, w_synthesis, gain, band_win_off, gain_tables)) return rc;
+    std::string text;
+    for (const auto& s : plan.bands) {
+        group_kernel_names(plan.bands[(size_t)s.group_leader], text);
+        text += "\n";
+    }
+    if (text.size() + 1 > n) return fail(UPX_ERR_INVALID, "upx_plan_kernel_names: %zu bytes needed", text.size() + 1);
+    std::memcpy(names, text.c_str(), text.size() + 1);
     return UPX_OK;
 }
 
@@ -879,7 +989,9 @@ void upx_plan_destroy(upx_plan* p) {
     }
     for (auto& kv : p->tw) (void)hipFree(kv.second);
     if (p->d_scalar) (void)hipFree(p->d_scalar);
+#if defined(UPX_EXPERIMENTS)
     if (p->d_pair_cnt) (void)hipFree(p->d_pair_cnt);
+#endif
     if (p->d_scratch) (void)hipFree(p->d_scratch);
     if (p->d_zoom) (void)hipFree(p->d_zoom);
     if (p->d_seam) (void)hipFree(p->d_seam);
@@ -962,6 +1074,485 @@ int upx_sync(upx_plan* p) {
     return UPX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// upx_process_device: one call = for every launch group, in list order,
+//   (1) geometry  - how the group's frames are cut into streams / launch pairs / chunks: host arithmetic only
+//                   (zoom_geometry, fused_geometry; the unfused path's is three lines inside launch_unfused),
+//   (2) tables    - what that geometry needs on the device: stream tables, dealing tables, seam buffer
+//                   (zoom_tables, zoom_deal_table, fused_tables; allocations and uploads, cached per geometry -
+//                   a repeated call sends nothing; upx_plan_reserve runs (1) + (2) ahead of the first call),
+//   (3) launch    - kernel arguments, events, launches (launch_unfused, zoom_launch, fused_launch; skipped on a dry run).
+// ---------------------------------------------------------------------------
+namespace {
+// one upx_process_device call as every launch group sees it
+struct Call {
+    const float* d_stereo;
+    float *d_c, *d_l, *d_r;
+    int64_t t_in, own_len, t_out;
+    bool dry;      // upx_plan_reserve: geometry + tables, nothing is launched and no buffer is touched
+    bool timing;   // HIP events around the launches
+    int slot;      // this call's slot of the event rings
+};
+// what one launch group covers: frames j < j_hi exist, hop-blocks m < m_hi are emitted; the first group of a call WRITES the
+// planes, every later one reads, adds and writes them back - list order = the reference's float32 band sum
+// ((0 + b0) + b1) + ... (center_extraction.py:508-511)
+struct Range {
+    long long j_hi, m_hi;
+    bool first;
+};
+
+// the plan's stream-seam buffer holds at least `floats` (grows only; growing waits for the stream: older launches read it)
+int ensure_seam(upx_plan* p, size_t floats) {
+    if (floats <= p->seam_floats) return UPX_OK;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (p->d_seam) HIP_TRY(hipFree(p->d_seam));
+    p->d_seam = nullptr;
+    p->seam_floats = 0;
+    HIP_TRY(hipMalloc(&p->d_seam, floats * sizeof(float)));
+    p->seam_floats = floats;
+    return UPX_OK;
+}
+// room for s.h_m0 on the device (grows only)
+int ensure_stream_table(upx_plan* p, BandState& s) {
+    if (s.h_m0.size() <= s.m0_cap) return UPX_OK;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (s.d_m0) HIP_TRY(hipFree(s.d_m0));
+    s.d_m0 = nullptr;
+    s.m0_cap = 0;
+    HIP_TRY(hipMalloc(&s.d_m0, s.h_m0.size() * sizeof(int)));
+    s.m0_cap = s.h_m0.size();
+    s.h_m0_sent.clear();
+    return UPX_OK;
+}
+
+// ---- unfused pipeline (upx_big.h): chunks of frames through the scratch ------------------------------------------------
+int launch_unfused(upx_plan* p, BandState& s, const Call& c, const Range& r) {
+    // a chunk transforms frames j0 .. j0+ch-1 (j0 odd): `halo` frames that only feed the first emitted blocks, `emit`
+    // emitted blocks, one trailing pair-partner frame
+    const int halo = (s.k - 1) | 1;
+    int emit = (s.chunk_frames - halo - 1) & ~1;
+    if ((long long)emit > r.m_hi) emit = (int)(r.m_hi + (r.m_hi & 1));
+    if (emit < 2) emit = 2;
+    const int ch = emit + halo + 1;
+    upx::BigArgs a;
+    a.in = reinterpret_cast<const upx::cf*>(c.d_stereo);
+    a.out_c = c.d_c; a.out_l = c.d_l; a.out_r = c.d_r;
+    a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw_n = s.d_tw_n; a.tw_rows = s.d_tw;
+    a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
+    a.z = p->d_scratch;
+    a.y = a.z + (size_t)ch * s.n;
+    a.yc = a.y + (size_t)ch * s.n;
+    a.t_in = (int)c.t_in; a.t_out = (int)c.t_out;
+    a.hop = s.hop; a.kf = s.k;
+    a.j_lo = 0; a.j_hi = (int)r.j_hi; a.ch = ch;
+    a.accumulate = r.first ? 0 : 1;
+    if (c.timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+    int n_chunks = 0;
+    for (long long m0 = 0; m0 < r.m_hi; m0 += emit, ++n_chunks) {
+        a.j0 = (int)m0 - halo;
+        a.m0 = (int)m0;
+        a.m1 = (int)(m0 + emit < r.m_hi ? m0 + emit : r.m_hi);
+        if (!c.dry) s.big->chunk(a, p->stream);
+    }
+    if (c.timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+    s.last_wg = n_chunks;
+    s.last_f = emit;
+    return UPX_OK;
+}
+
+// ---- band-limited path (upx_zoom.h) ---------------------------------------------------------------------------------
+// Launch pairs (analysis, synthesis) over consecutive runs of frame pairs (what the scratch holds), and the streams of
+// each; the tables hold the first frame of every Ls/Rs stream and of every centre stream, launch after launch, + the end
+// frame.  Streams cover frames -1 .. m_hi-1; stream tails go through the seam buffer.
+struct ZoomLaunch {
+    long long pair0, pair_end;
+    int s0_lr, ns_lr, s0_c, ns_c;
+    bool once;
+};
+struct ZoomGeometry {
+    std::vector<ZoomLaunch> launches;
+    std::vector<int> tab_lr, tab_c;
+    long long n_lr = 0, n_c = 0;   // streams of either role over all launch pairs
+    long long tail = 0;            // (K - 1) hop samples a stream leaves for its successor
+    int groups = 1, res_s = 1;     // residue groups of a frame; synthesis workgroups a CU holds
+};
+
+void zoom_geometry(const upx_plan* p, const BandState& s, long long m_hi, ZoomGeometry& g) {
+    const long long frames = m_hi + 1;
+    const long long pairs_total = (frames + 1) / 2;
+    const int cap = zoom_frames_cap(p, s.zoom_p);
+    g.groups = s.zoom_d / s.zoom->rg;
+    g.res_s = zoom_resident(s);
+    g.tail = (long long)(s.k - 1) * s.hop;
+    // n streams over n_pairs frame pairs, lengths within one pair of each other - except the stream that holds the
+    // signal's first frame and the one that holds its last: they run the synthesis' signal-edge flavour (per-sample
+    // checks on every transform: 15-25 % slower, scripts/phase_prof/zwgtime.hip) and get `edge` of the others' length
+    const double edge = p->knob_zoom_edge_percent >= 50 && p->knob_zoom_edge_percent < 100 ? p->knob_zoom_edge_percent / 100.0 : 1.0;
+    auto deal = [edge](std::vector<int>& tab, long long pair0, long long n_pairs, long long n, bool first, bool last,
+                       long long min_pairs) {
+        const double w_first = first && n >= 8 ? edge : 1.0, w_last = last && n >= 8 ? edge : 1.0;
+        const double total = (double)(n - 2) + w_first + w_last;
+        long long prev = 0;
+        for (long long i = 0; i < n; ++i) {
+            const double before = i == 0 ? 0.0 : w_first + (double)(i - 1);
+            long long q = n >= 8 ? (long long)((double)n_pairs * before / total) : n_pairs * i / n;
+            if (i > 0 && q < prev + min_pairs) q = prev + min_pairs;   // (rounding; a stream holds a tail)
+            tab.push_back((int)(-1 + 2 * (pair0 + q)));
+            prev = q;
+        }
+    };
+    const bool once = p->knob_zoom_once != 0 && s.blocks_override <= 0 && p->knob_zoom_f <= 0;
+    if (once) {
+        // Every resident workgroup slot once (ZoomArgs): W workgroups per residue group, centre streams longer
+        // than the Ls/Rs ones by the ratio of what a frame costs either role, so that all end together.
+        const long long n_launch = (2 * pairs_total + cap - 1) / cap;
+        const long long W = (long long)p->n_cu * g.res_s / g.groups;
+        const double ratio = p->knob_zoom_c_cost > 0.05 && p->knob_zoom_c_cost < 1.0 ? p->knob_zoom_c_cost : 0.55;
+        const long long min_pairs = (s.k + 1) / 2 > 8 ? (s.k + 1) / 2 : 8;   // a stream holds a tail; short ones are all prologue
+        for (long long L = 0; L < n_launch; ++L) {
+            const long long q0 = pairs_total * L / n_launch, q1 = pairs_total * (L + 1) / n_launch;
+            const long long np = q1 - q0;
+            long long n_c = (long long)std::llround((double)W * ratio / (1.0 + ratio)), n_lr = W - n_c;
+            if (n_lr > np / min_pairs) n_lr = np / min_pairs;
+            if (n_c > np / (2 * min_pairs)) n_c = np / (2 * min_pairs);
+            if (n_lr < 1) n_lr = 1;
+            if (n_c < 1) n_c = 1;
+            g.launches.push_back(ZoomLaunch{q0, q1, (int)g.tab_lr.size(), (int)n_lr, (int)g.tab_c.size(), (int)n_c,
+                                            (n_lr + n_c) * g.groups > (long long)p->n_cu * (g.res_s - 1)});
+            deal(g.tab_lr, q0, np, n_lr, L == 0, L == n_launch - 1, min_pairs);
+            deal(g.tab_c, q0, np, n_c, L == 0, L == n_launch - 1, min_pairs);
+        }
+    } else {
+        // streams of F frames for both roles, about UPX_ZOOM_FILL x the slots of them (the scheme of rounds 1-2;
+        // upx_plan_set_blocks_per_stream and UPX_ZOOM_F choose F)
+        const long long want = zoom_streams_wanted(p, s);
+        long long f = s.blocks_override > 0 ? s.blocks_override : (frames + want - 1) / want;
+        if (s.blocks_override <= 0) {
+            if (p->knob_zoom_f > 0) f = p->knob_zoom_f;
+            else if (f < 16) f = 16;
+            if (f > 48 && p->knob_zoom_f <= 0) f = 48;
+        }
+        if (f < s.k) f = s.k;
+        f += f & 1;
+        if (f > cap) f = cap;
+        const long long n_streams = (frames + f - 1) / f, per_launch = cap / f;
+        for (long long s0 = 0; s0 < n_streams; s0 += per_launch) {
+            const long long ns = n_streams - s0 < per_launch ? n_streams - s0 : per_launch;
+            g.launches.push_back(ZoomLaunch{s0 * f / 2, (s0 + ns) * f / 2, (int)s0, (int)ns, (int)s0, (int)ns, false});
+            for (long long i = 0; i < ns; ++i) g.tab_lr.push_back((int)(-1 + (s0 + i) * f));
+        }
+        g.tab_c = g.tab_lr;
+    }
+    const int end_frame = (int)(-1 + 2 * g.launches.back().pair_end);
+    g.tab_lr.push_back(end_frame);
+    g.tab_c.push_back(end_frame);
+    g.n_lr = (long long)g.tab_lr.size() - 1;
+    g.n_c = (long long)g.tab_c.size() - 1;
+}
+
+// the two stream tables next to each other on the device, the seam buffer large enough
+int zoom_tables(upx_plan* p, BandState& s, const ZoomGeometry& g) {
+    s.h_m0 = g.tab_lr;
+    s.h_m0.insert(s.h_m0.end(), g.tab_c.begin(), g.tab_c.end());
+    if (int rc = ensure_stream_table(p, s)) return rc;
+    if (s.h_m0 != s.h_m0_sent) {
+        // in stream order behind the previous call's kernels, which read the old table; the source is pageable, so the
+        // call returns when it has been read (tracks of unequal length change the geometry call after call: no
+        // synchronisation here, the uploads and downloads of the neighbouring tracks keep running)
+        HIP_TRY(hipMemcpyAsync(s.d_m0, s.h_m0.data(), s.h_m0.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
+        s.h_m0_sent = s.h_m0;
+    }
+    return ensure_seam(p, (size_t)(2 * g.n_lr + g.n_c) * g.tail);
+}
+
+// The analysis fills every resident slot once and its older workgroups, which still end first, take more pairs
+// (ZoomArgs::deal_rows): pair after pair to the workgroup that would end first, round r of the `res` dispatch rounds
+// running at 1 - r age of the first round's speed; ties go to the older workgroup, so the counts never increase with l.
+// Cached per (pairs of an XCD's share, workgroups per XCD, rounds).
+int zoom_deal_table(upx_plan* p, BandState& s, long long np_xcd, long long per_xcd, int res, const BandState::Deal** out) {
+    const long long key = np_xcd * 4096 + per_xcd * 8 + res;
+    for (const auto& d : s.deals)
+        if (d.key == key) {
+            *out = &d;
+            return UPX_OK;
+        }
+    const int n_l = (int)per_xcd, per_round = n_l / res;
+    std::vector<int> count(n_l, 0);
+    std::vector<double> cost(n_l);
+    for (int l = 0; l < n_l; ++l) {
+        const int r = l / per_round < res ? l / per_round : res - 1;
+        cost[l] = 1.0 / (1.0 - r * p->knob_zoom_a_age / 100.0);
+    }
+    for (long long k = 0; k < np_xcd; ++k) {
+        int best = 0;
+        double t_best = 1e300;
+        for (int l = 0; l < n_l; ++l) {
+            const double t = (count[l] + 1) * cost[l];
+            if (t < t_best - 1e-9) { t_best = t; best = l; }
+        }
+        ++count[best];
+    }
+    BandState::Deal d;
+    d.key = key;
+    d.rows = count[n_l - 1];
+    std::vector<int> tab(2 * (size_t)n_l);
+    int behind = 0;
+    for (int l = 0; l < n_l; ++l) {
+        tab[2 * l] = behind;
+        tab[2 * l + 1] = count[l] - d.rows;
+        behind += tab[2 * l + 1];
+    }
+    if (s.deals.size() >= 8) {   // (geometries come and go: start over)
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        for (auto& old : s.deals) (void)hipFree(old.d_tab);
+        s.deals.clear();
+    }
+    HIP_TRY(hipMalloc(&d.d_tab, tab.size() * sizeof(int)));
+    HIP_TRY(hipMemcpy(d.d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+    s.deals.push_back(d);
+    *out = &s.deals.back();
+    return UPX_OK;
+}
+
+int zoom_launch(upx_plan* p, BandState& s, const Call& c, const Range& r, const ZoomGeometry& g) {
+    upx::ZoomArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const upx::cf*>(c.d_stereo);
+    a.out_c = c.d_c; a.out_l = c.d_l; a.out_r = c.d_r;
+    a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw = s.d_tw; a.ramp = s.d_ramp;
+    a.seam = p->d_seam;
+    a.seam_c = p->d_seam + (size_t)2 * g.n_lr * g.tail;
+    a.stream_m0 = s.d_m0;
+    a.stream_m0_c = s.d_m0 + g.n_lr + 1;
+    a.n = s.n; a.d = s.zoom_d; a.hop = s.hop;
+    a.t_in = (int)c.t_in; a.t_out = (int)c.t_out;
+    a.j_lo = 0; a.j_hi = (int)r.j_hi; a.m_lo = 0; a.m_hi = (int)r.m_hi;
+    a.blocks_per_stream = g.tab_lr[1] - g.tab_lr[0];
+    a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
+    a.accumulate = r.first ? 0 : 1;
+    const int res_a = zoom_resident(s, true);
+    const long long slots = (long long)p->n_cu * res_a;
+    if (c.timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+    const bool split = c.timing && 2 * (long long)g.launches.size() - 1 <= kMidEvents;
+    int n_mid = 0;
+    hipEvent_t* mid = s.ring_mid.data() + (size_t)c.slot * kMidEvents;
+    int n_launches = 0;
+    for (const ZoomLaunch& L : g.launches) {
+        a.stream0 = L.s0_lr; a.ns_lr = L.ns_lr;
+        a.stream0_c = L.s0_c; a.ns_c = L.ns_c;
+        a.f0 = (int)(-1 + 2 * L.pair0);
+        a.pair0 = (int)L.pair0;
+        a.pair_end = (int)L.pair_end;
+        const long long pairs = L.pair_end - L.pair0;
+        a.y = p->d_zoom;
+        a.yc = p->d_zoom + (size_t)(2 * pairs) * s.zoom_p;
+        // analysis grid: every resident slot once, 8 x (workgroups per XCD label), see zoom_analysis_program
+        long long per_xcd = (slots + 7) / 8;
+        if (per_xcd > (pairs + 7) / 8) per_xcd = (pairs + 7) / 8;
+        if (per_xcd < 1) per_xcd = 1;
+        a.pairs_per_wg = (int)per_xcd;
+        // its workgroups take the top priority in turn (ZoomArgs) ...
+        a.prio_split = (p->knob_prio_young > 0 && res_a >= 2 && res_a <= 4 && 8 * per_xcd >= (long long)p->n_cu * res_a)
+                           ? p->n_cu : 0;
+        a.prio_rounds = res_a;
+        // ... and the older ones take more pairs
+        a.deal_rows = 0;
+        const long long np_xcd = (pairs + 7) / 8;      // pairs of an XCD's share (zoom_analysis_program)
+        if (a.prio_split > 0 && p->knob_zoom_a_age > 0 && p->knob_zoom_a_age < 40 && np_xcd >= 4 * per_xcd) {
+            const BandState::Deal* deal = nullptr;
+            if (int rc = zoom_deal_table(p, s, np_xcd, per_xcd, res_a, &deal)) return rc;
+            a.deal_rows = deal->rows;
+            a.deal_tab = deal->d_tab;
+        }
+        // ... and so does the synthesis when its streams were cut for that
+        a.prio_split_s = (p->knob_prio_young > 0 && L.once && g.res_s >= 2 && g.res_s <= 4) ? p->n_cu : 0;
+        a.prio_rounds_s = g.res_s;
+        if (n_launches == 0) {
+            s.fill_wg = (int)((L.ns_lr + L.ns_c) * g.groups);
+            s.fill_slots = p->n_cu * g.res_s;
+            s.fill_wg_a = (int)(8 * per_xcd);
+            s.fill_slots_a = (int)slots;
+        }
+        if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
+        if (!c.dry) s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
+        if (split) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
+        if (!c.dry) s.zoom->synthesis(a, g.groups, p->stream);
+        ++n_launches;
+    }
+    if (c.timing) s.ring_mid_n[c.slot] = n_mid;
+    if (!c.dry && (g.n_lr > 1 || g.n_c > 1)) {
+        if (seam_vec_ok(p, c.d_c, c.d_l, c.d_r, s.hop) && g.n_lr + g.n_c <= 65535)
+            hipLaunchKernelGGL(upx_zoom_seam_add4_kernel, dim3((unsigned)((g.tail / 4 + 255) / 256), (unsigned)(g.n_lr + g.n_c)),
+                               dim3(256), 0, p->stream, a, (int)g.n_lr, (int)g.n_c, (int)g.tail);
+        else
+            hipLaunchKernelGGL(upx_zoom_seam_add_kernel, dim3(grid_for((g.n_lr + g.n_c) * g.tail)), dim3(256), 0,
+                               p->stream, a, (int)g.n_lr, (int)g.n_c, (int)g.tail);
+    }
+    if (c.timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+    s.last_wg = (int)((g.n_lr + g.n_c) * g.groups);
+    s.last_f = g.tab_lr[1] - g.tab_lr[0];
+    return UPX_OK;
+}
+
+// ---- fused streaming kernel (upx_core.h) ------------------------------------------------------------------------------
+struct FusedGeometry {
+    long long f = 0;          // frames per stream (of the interior streams when `uneven`)
+    long long n_streams = 0, n_wg = 0;
+    long long slots = 0;      // workgroups resident at once
+    long long tail = 0;
+    bool uneven = false;      // streams of unequal length: m0 holds every stream's first frame (+ the end)
+    std::vector<int> m0;
+};
+
+// blocks per stream: fill every resident workgroup slot once; even (whole frame pairs), at least UPX_MIN_STREAM_FRAMES and
+// at least K (a stream's tail must end inside the next stream).  Streams cover frames m_lo-1 .. m_hi-1.
+void fused_geometry(const upx_plan* p, const BandState& s, long long m_hi, FusedGeometry& g) {
+    const long long target_streams = max_auto_streams(p, s);
+    long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + 1 + target_streams - 1) / target_streams;
+    if (s.blocks_override <= 0 && f < p->knob_min_stream_frames) f = p->knob_min_stream_frames;
+    if (f < s.k) f = s.k;
+    f += f & 1;
+    g.n_streams = (m_hi + 1 + f - 1) / f;
+    g.n_wg = (g.n_streams + s.kern->g - 1) / s.kern->g;
+    g.tail = (long long)(s.k - 1) * s.hop;
+    // A launch that fills the machine: the first and the last workgroups run the signal-edge flavour (~12 % slower per
+    // frame; measured per workgroup, scripts/phase_prof/wgtime.hip) and the launch used to wait for them.  They get
+    // streams of edge_percent of the others' length; the others grow by what that frees (stream table, BandArgs).
+    const int G = s.kern->g;
+    g.slots = target_streams / G;
+    const long long slots = g.slots, total = m_hi + 1;         // frames -1 .. m_hi-1
+    if (s.blocks_override <= 0 && p->knob_edge_percent < 100 && p->knob_edge_percent >= 50 && slots >= 8 &&
+        total >= slots * G * 16) {
+        const double share = p->knob_edge_percent / 100.0;
+        long long fu = (long long)std::ceil((double)total / ((double)G * ((double)slots - 2.0 * (1.0 - share))));
+        fu += fu & 1;
+        for (int attempt = 0; attempt < 8 && !g.uneven; ++attempt, fu += 2) {
+            long long fe = (long long)(share * (double)fu);
+            fe -= fe & 1;
+            if (fe < s.k + (s.k & 1) || fe < 2) break;
+            std::vector<long long> len{fe};
+            long long remaining = total - G * fe;
+            while (remaining > G * fe) {
+                len.push_back(fu);
+                remaining -= G * fu;
+            }
+            if (remaining > 0) {
+                long long last = (remaining + G - 1) / G;
+                last += last & 1;
+                if (last < s.k + (s.k & 1)) last = s.k + (s.k & 1);
+                len.push_back(last);
+            }
+            if ((long long)len.size() > slots) continue;        // one workgroup too many: longer streams
+            g.m0.assign(len.size() * G + 1, 0);
+            g.m0[0] = -1;
+            for (size_t w = 0; w < len.size(); ++w)
+                for (int q = 0; q < G; ++q) g.m0[w * G + q + 1] = g.m0[w * G + q] + (int)len[w];
+            g.n_wg = (long long)len.size();
+            g.n_streams = g.n_wg * G;
+            f = fu;
+            g.uneven = true;
+        }
+    }
+    g.f = f;
+}
+
+int fused_tables(upx_plan* p, BandState& s, const FusedGeometry& g) {
+    if (g.uneven) {
+        // the table goes to the device on the plan's stream, ordered with the launch (the host copy stays in the plan)
+        s.h_m0 = g.m0;
+        if (int rc = ensure_stream_table(p, s)) return rc;
+        if (s.h_m0 != s.h_m0_sent) {   // (a repeated call on the same geometry - every step of a benchmark - sends nothing)
+            HIP_TRY(hipMemcpyAsync(s.d_m0, s.h_m0.data(), s.h_m0.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipStreamSynchronize(p->stream));   // the host copy may change on the next call
+            s.h_m0_sent = s.h_m0;
+        }
+    }
+    return ensure_seam(p, (size_t)g.n_wg * s.kern->g * 3 * g.tail);
+}
+
+int fused_launch(upx_plan* p, BandState& s, const Call& c, const Range& r, const FusedGeometry& g) {
+    upx::BandArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.in = reinterpret_cast<const upx::cf*>(c.d_stereo);
+    a.out_c = c.d_c; a.out_l = c.d_l; a.out_r = c.d_r;
+    a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw = s.d_tw;
+    a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
+    a.t_in = (int)c.t_in; a.t_out = (int)c.t_out;
+    a.j_lo = 0; a.j_hi = (int)r.j_hi; a.m_lo = 0; a.m_hi = (int)r.m_hi;
+    a.blocks_per_stream = (int)g.f;
+    a.stream_m0 = g.uneven ? s.d_m0 : nullptr;
+    a.accumulate = r.first ? 0 : 1;
+    a.seam = p->d_seam;
+    // one-wave workgroups that fill the machine: the first `SIMDs` of them are the older wave of their SIMD
+    // (BandArgs::prio_split) ... and two-wave workgroups (N = 2048: four per CU) run at four speeds by dispatch round; the
+    // rounds take the top priority in turn (prio_split < 0: workgroups per round)
+    a.prio_split = 0;
+    if (p->knob_prio_young > 0 && p->knob_prio_young < 4) {
+        if (s.kern->wg == 64 && g.n_wg > 4LL * p->n_cu) a.prio_split = 4 * p->n_cu;
+        else if (s.kern->wg == 128 && g.n_wg > 2LL * p->n_cu) a.prio_split = -p->n_cu;
+    }
+    a.prio_young = p->knob_prio_young;
+    bool seam_inside = false;
+#if defined(UPX_EXPERIMENTS)
+    // stream seams inside the launch (seam_epilogue; rejected in round 5: the agent-scope release / acquire it needs costs
+    // more than the launch it saves): UPX_SEAM_INKERNEL = 1 always, 2 when the launch does not fill the chip, 0 never
+    seam_inside = g.n_streams > 1 && p->d_pair_cnt && g.n_wg <= (long long)p->pair_cnt_n &&
+                  (p->knob_seam_inkernel == 1 || (p->knob_seam_inkernel == 2 && g.n_wg <= g.slots));
+    a.pair_cnt = seam_inside ? p->d_pair_cnt : nullptr;
+    a.n_streams = (int)g.n_streams;
+#endif
+    s.last_wg = (int)g.n_wg;
+    s.last_f = (int)g.f;
+    s.fill_wg = (int)g.n_wg;
+    s.fill_slots = (int)g.slots;
+    s.fill_wg_a = s.fill_slots_a = 0;
+    if (c.timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
+    if (!c.dry) s.kern->launch(a, (int)g.n_wg, p->stream);
+    if (!c.dry && g.n_streams > 1 && !seam_inside) {
+        if (seam_vec_ok(p, c.d_c, c.d_l, c.d_r, s.hop) && g.n_streams <= 65535)
+            hipLaunchKernelGGL(upx_stream_seam_add4_kernel, dim3((unsigned)((g.tail / 4 + 255) / 256), (unsigned)g.n_streams), dim3(256), 0,
+                               p->stream, a, (int)g.n_streams, (int)g.tail, s.hop);
+        else
+            hipLaunchKernelGGL(upx_stream_seam_add_kernel, dim3(grid_for(g.n_streams * g.tail)), dim3(256), 0, p->stream, a,
+                               (int)g.n_streams, (int)g.tail, s.hop);
+    }
+    if (c.timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+    return UPX_OK;
+}
+
+// what the band / launch reports read (upx_plan_band_info, _band_fill): kept across calls that must not show in them -
+// upx_plan_reserve's dry run and its warm-up call on a few frames of silence
+struct Reports {
+    std::vector<std::tuple<int, int, int, int, int, int>> v;
+    explicit Reports(const upx_plan* p) {
+        for (const auto& s : p->bands) v.emplace_back(s.last_wg, s.last_f, s.fill_wg, s.fill_slots, s.fill_wg_a, s.fill_slots_a);
+    }
+    void restore(upx_plan* p) const {
+        for (size_t i = 0; i < p->bands.size() && i < v.size(); ++i)
+            std::tie(p->bands[i].last_wg, p->bands[i].last_f, p->bands[i].fill_wg, p->bands[i].fill_slots, p->bands[i].fill_wg_a,
+                     p->bands[i].fill_slots_a) = v[i];
+    }
+};
+
+// the launch groups of a plan in the order they run
+void launch_order(const upx_plan* p, std::vector<size_t>& order) {
+    for (size_t b = 0; b < p->bands.size(); ++b)
+        if (p->bands[b].group_size > 0) order.push_back(b);      // (members are carried by their group leader's launch)
+#if defined(UPX_EXPERIMENTS)
+    // UPX_FIRST_BAND = k launches the group that carries band k first; UPX_BAND_ROTATE starts that many groups into the
+    // list: the same sum in another float32 association (round-4 / round-5 A/Bs; the product library cannot do this)
+    const int fb = p->knob_first_band;
+    if (fb >= 0 && fb < (int)p->bands.size()) {
+        const size_t lead = (size_t)p->bands[(size_t)fb].group_leader;
+        auto it = std::find(order.begin(), order.end(), lead);
+        if (it != order.end()) std::rotate(order.begin(), it, it + 1);
+    }
+    if (p->knob_band_rotate > 0 && !order.empty())
+        std::rotate(order.begin(), order.begin() + (p->knob_band_rotate % (int)order.size()), order.end());
+#endif
+}
+}   // namespace
+
 int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t own_len, float* d_c, float* d_l,
                        float* d_r, int64_t t_out) {
     if (!p || t_in < 0 || own_len < 0 || t_out < 0) return fail(UPX_ERR_INVALID, "upx_process_device: bad argument");
@@ -981,427 +1572,56 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
         for (auto& s : p->bands) s.last_wg = 0;
         return UPX_OK;
     }
-    const bool timing = p->timing && !dry;
-    const int slot = (int)(p->timed_calls % kTimingSlots);
-    for (size_t b = 0; b < p->bands.size(); ++b) {
-        BandState& s = p->bands[b];
+    const Call c{d_stereo, d_c, d_l, d_r, t_in, own_len, t_out, dry, p->timing && !dry, (int)(p->timed_calls % kTimingSlots)};
+    // a dry run reports nothing: the band / launch reports (last_wg, fill_*) keep describing the last REAL call
+    const Reports kept(p);
+    for (auto& s : p->bands) {
         s.last_wg = 0;
-        if (dry) continue;
-        s.ev0 = s.ring0[slot];
-        s.ev1 = s.ring1[slot];
-        s.ring_used[slot] = 0;
+        if (!c.timing) continue;     // (ev0 / ev1 stay the events of the last TIMED call: upx_plan_band_times_ms reads them)
+        s.ev0 = s.ring0[c.slot];
+        s.ev1 = s.ring1[c.slot];
+        s.ring_used[c.slot] = 0;
     }
-    // Launch order.  The first launch writes the planes, every later one reads, adds and writes them back (the band sum);
-    // list order gives the reference's float32 association ((0 + b0) + b1) + ... (center_extraction.py:508-511).
-    // UPX_FIRST_BAND = k (experiment, read at plan creation) launches the group that carries band k first: the same
-    // sum in another association (differences ~1e-8), the plane read moved from that launch to the list's first one.
     std::vector<size_t> order;
-    {
-        const int fb = p->knob_first_band;
-        const size_t lead = fb >= 0 && fb < (int)p->bands.size() ? (size_t)p->bands[(size_t)fb].group_leader : 0;
-        if (lead != 0) order.push_back(lead);
-        for (size_t b = 0; b < p->bands.size(); ++b)
-            if (b != lead || lead == 0) order.push_back(b);
-    }
-    if (p->knob_band_rotate > 0) {
-        std::vector<size_t> leaders;
-        for (size_t b : order)
-            if (p->bands[b].group_size > 0) leaders.push_back(b);
-        std::rotate(leaders.begin(), leaders.begin() + (p->knob_band_rotate % (int)leaders.size()), leaders.end());
-        order = leaders;
-    }
-    const size_t first_launch = order.front();
+    launch_order(p, order);
+    int rc = UPX_OK;
     for (size_t b : order) {
         BandState& s = p->bands[b];
-        if (s.group_size == 0) continue;                              // carried by its group leader's launch
-        const long long j_hi = (own_len + s.hop - 1) / s.hop;       // frames with j*hop < own_len
-        const long long m_all = (t_out + s.hop - 1) / s.hop;        // hop-blocks that intersect [0, t_out)
-        long long m_hi = j_hi + s.k - 1 < m_all ? j_hi + s.k - 1 : m_all;
-        if (b == first_launch) m_hi = m_all;                        // the first launch initialises every output sample
-        if (j_hi > 0x7fffffffLL || m_all > 0x7fffffffLL) return fail(UPX_ERR_INVALID, "signal too long for int32 frame index");
-        if (m_hi <= 0) continue;
+        Range r;
+        r.first = b == order.front();
+        r.j_hi = (own_len + s.hop - 1) / s.hop;                          // frames with j*hop < own_len
+        const long long m_all = (t_out + s.hop - 1) / s.hop;            // hop-blocks that intersect [0, t_out)
+        r.m_hi = r.j_hi + s.k - 1 < m_all ? r.j_hi + s.k - 1 : m_all;
+        if (r.first) r.m_hi = m_all;                                    // the first launch initialises every output sample
+        if (r.j_hi > 0x7fffffffLL || m_all > 0x7fffffffLL) { rc = fail(UPX_ERR_INVALID, "signal too long for int32 frame index"); break; }
+        if (r.m_hi <= 0) continue;
         if (s.big) {
-            // chunked unfused path: a chunk transforms frames j0 .. j0+ch-1 (j0 odd): `halo` frames that only
-            // feed the first emitted blocks, `emit` emitted blocks, one trailing pair-partner frame
-            const int halo = (s.k - 1) | 1;
-            int emit = (s.chunk_frames - halo - 1) & ~1;
-            if ((long long)emit > m_hi) emit = (int)(m_hi + (m_hi & 1));
-            if (emit < 2) emit = 2;
-            const int ch = emit + halo + 1;
-            upx::BigArgs a;
-            a.in = reinterpret_cast<const upx::cf*>(d_stereo);
-            a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
-            a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw_n = s.d_tw_n; a.tw_rows = s.d_tw;
-            a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
-            a.z = p->d_scratch;
-            a.y = a.z + (size_t)ch * s.n;
-            a.yc = a.y + (size_t)ch * s.n;
-            a.t_in = (int)t_in; a.t_out = (int)t_out;
-            a.hop = s.hop; a.kf = s.k;
-            a.j_lo = 0; a.j_hi = (int)j_hi; a.ch = ch;
-            a.accumulate = b == first_launch ? 0 : 1;
-            if (timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
-            int n_chunks = 0;
-            for (long long m0 = 0; m0 < m_hi; m0 += emit, ++n_chunks) {
-                a.j0 = (int)m0 - halo;
-                a.m0 = (int)m0;
-                a.m1 = (int)(m0 + emit < m_hi ? m0 + emit : m_hi);
-                if (!dry) s.big->chunk(a, p->stream);
-            }
-            if (timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
-            s.last_wg = n_chunks;
-            s.last_f = emit;
-            continue;
+            rc = launch_unfused(p, s, c, r);
+        } else if (s.zoom) {
+            ZoomGeometry g;
+            zoom_geometry(p, s, r.m_hi, g);
+            rc = zoom_tables(p, s, g);
+            if (rc == UPX_OK) rc = zoom_launch(p, s, c, r, g);
+        } else {
+            FusedGeometry g;
+            fused_geometry(p, s, r.m_hi, g);
+            rc = fused_tables(p, s, g);
+            if (rc == UPX_OK) rc = fused_launch(p, s, c, r, g);
         }
-        if (s.zoom) {
-            // band-limited path: per launch pair, analysis of the frames of a run of streams, then their synthesis;
-            // streams cover frames -1 .. m_hi-1 in runs of F (even); stream tails go through the seam buffer
-            const long long frames = m_hi + 1;
-            const long long pairs_total = (frames + 1) / 2;
-            const int cap = zoom_frames_cap(p, s.zoom_p);
-            const int groups = s.zoom_d / s.zoom->rg;
-            const int res_s = zoom_resident(s);
-            const long long tail = (long long)(s.k - 1) * s.hop;
-            // Launch pairs (analysis, synthesis) over consecutive runs of frame pairs (what the scratch holds), and the streams
-            // of each; the tables hold the first frame of every Ls/Rs stream and of every centre stream, launch after launch.
-            struct Launch { long long pair0, pair_end; int s0_lr, ns_lr, s0_c, ns_c; bool once; };
-            std::vector<Launch> launches;
-            std::vector<int> tab_lr, tab_c;
-            // n streams over n_pairs frame pairs, lengths within one pair of each other - except the stream that holds the
-            // signal's first frame and the one that holds its last: they run the synthesis' signal-edge flavour (per-sample
-            // checks on every transform: 15-25 % slower, scripts/phase_prof/zwgtime.hip) and get `edge` of the others' length
-            const double edge = p->knob_zoom_edge_percent >= 50 && p->knob_zoom_edge_percent < 100 ? p->knob_zoom_edge_percent / 100.0 : 1.0;
-            auto deal = [edge](std::vector<int>& tab, long long pair0, long long n_pairs, long long n, bool first, bool last,
-                               long long min_pairs) {
-                const double w_first = first && n >= 8 ? edge : 1.0, w_last = last && n >= 8 ? edge : 1.0;
-                const double total = (double)(n - 2) + w_first + w_last;
-                long long prev = 0;
-                for (long long i = 0; i < n; ++i) {
-                    const double before = i == 0 ? 0.0 : w_first + (double)(i - 1);
-                    long long q = n >= 8 ? (long long)((double)n_pairs * before / total) : n_pairs * i / n;
-                    if (i > 0 && q < prev + min_pairs) q = prev + min_pairs;   // (rounding; a stream holds a tail)
-                    tab.push_back((int)(-1 + 2 * (pair0 + q)));
-                    prev = q;
-                }
-            };
-            const bool once = p->knob_zoom_once != 0 && s.blocks_override <= 0 && p->knob_zoom_f <= 0;
-            if (once) {
-                // Every resident workgroup slot once (ZoomArgs): W workgroups per residue group, centre streams longer
-                // than the Ls/Rs ones by the ratio of what a frame costs either role, so that all end together.
-                const long long n_launch = (2 * pairs_total + cap - 1) / cap;
-                const long long W = (long long)p->n_cu * res_s / groups;
-                const double r = p->knob_zoom_c_cost > 0.05 && p->knob_zoom_c_cost < 1.0 ? p->knob_zoom_c_cost : 0.55;
-                const long long min_pairs = (s.k + 1) / 2 > 8 ? (s.k + 1) / 2 : 8;   // a stream holds a tail; short ones are all prologue
-                for (long long L = 0; L < n_launch; ++L) {
-                    const long long q0 = pairs_total * L / n_launch, q1 = pairs_total * (L + 1) / n_launch;
-                    const long long np = q1 - q0;
-                    long long n_c = (long long)std::llround((double)W * r / (1.0 + r)), n_lr = W - n_c;
-                    if (n_lr > np / min_pairs) n_lr = np / min_pairs;
-                    if (n_c > np / (2 * min_pairs)) n_c = np / (2 * min_pairs);
-                    if (n_lr < 1) n_lr = 1;
-                    if (n_c < 1) n_c = 1;
-                    launches.push_back(Launch{q0, q1, (int)tab_lr.size(), (int)n_lr, (int)tab_c.size(), (int)n_c,
-                                              (n_lr + n_c) * groups > (long long)p->n_cu * (res_s - 1)});
-                    deal(tab_lr, q0, np, n_lr, L == 0, L == n_launch - 1, min_pairs);
-                    deal(tab_c, q0, np, n_c, L == 0, L == n_launch - 1, min_pairs);
-                }
-            } else {
-                // streams of F frames for both roles, about UPX_ZOOM_FILL x the slots of them (the scheme of rounds 1-2;
-                // upx_plan_set_blocks_per_stream and UPX_ZOOM_F choose F)
-                const long long want = zoom_streams_wanted(p, s);
-                long long f = s.blocks_override > 0 ? s.blocks_override : (frames + want - 1) / want;
-                if (s.blocks_override <= 0) {
-                    if (p->knob_zoom_f > 0) f = p->knob_zoom_f;
-                    else if (f < 16) f = 16;
-                    if (f > 48 && p->knob_zoom_f <= 0) f = 48;
-                }
-                if (f < s.k) f = s.k;
-                f += f & 1;
-                if (f > cap) f = cap;
-                const long long n_streams = (frames + f - 1) / f, per_launch = cap / f;
-                for (long long s0 = 0; s0 < n_streams; s0 += per_launch) {
-                    const long long ns = n_streams - s0 < per_launch ? n_streams - s0 : per_launch;
-                    launches.push_back(Launch{s0 * f / 2, (s0 + ns) * f / 2, (int)s0, (int)ns, (int)s0, (int)ns, false});
-                    for (long long i = 0; i < ns; ++i) tab_lr.push_back((int)(-1 + (s0 + i) * f));
-                }
-                tab_c = tab_lr;
-            }
-            const int end_frame = (int)(-1 + 2 * launches.back().pair_end);
-            tab_lr.push_back(end_frame);
-            tab_c.push_back(end_frame);
-            const long long n_lr_total = (long long)tab_lr.size() - 1, n_c_total = (long long)tab_c.size() - 1;
-            // the tables live next to each other on the device; a repeated call on the same geometry sends nothing
-            s.h_m0 = tab_lr;
-            s.h_m0.insert(s.h_m0.end(), tab_c.begin(), tab_c.end());
-            if (s.h_m0.size() > s.m0_cap) {
-                HIP_TRY(hipStreamSynchronize(p->stream));
-                if (s.d_m0) HIP_TRY(hipFree(s.d_m0));
-                s.d_m0 = nullptr;
-                s.m0_cap = 0;
-                HIP_TRY(hipMalloc(&s.d_m0, s.h_m0.size() * sizeof(int)));
-                s.m0_cap = s.h_m0.size();
-                s.h_m0_sent.clear();
-            }
-            if (s.h_m0 != s.h_m0_sent) {
-                // in stream order behind the previous call's kernels, which read the old table; the source is pageable, so the
-                // call returns when it has been read (tracks of unequal length change the geometry call after call: no
-                // synchronisation here, the uploads and downloads of the neighbouring tracks keep running)
-                HIP_TRY(hipMemcpyAsync(s.d_m0, s.h_m0.data(), s.h_m0.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
-                s.h_m0_sent = s.h_m0;
-            }
-            const size_t seam_need = (size_t)(2 * n_lr_total + n_c_total) * tail;
-            if (seam_need > p->seam_floats) {
-                HIP_TRY(hipStreamSynchronize(p->stream));
-                if (p->d_seam) HIP_TRY(hipFree(p->d_seam));
-                p->d_seam = nullptr;
-                p->seam_floats = 0;
-                HIP_TRY(hipMalloc(&p->d_seam, seam_need * sizeof(float)));
-                p->seam_floats = seam_need;
-            }
-            upx::ZoomArgs a;
-            std::memset(&a, 0, sizeof a);
-            a.in = reinterpret_cast<const upx::cf*>(d_stereo);
-            a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
-            a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw = s.d_tw; a.ramp = s.d_ramp;
-            a.seam = p->d_seam;
-            a.seam_c = p->d_seam + (size_t)2 * n_lr_total * tail;
-            a.stream_m0 = s.d_m0;
-            a.stream_m0_c = s.d_m0 + n_lr_total + 1;
-            a.n = s.n; a.d = s.zoom_d; a.hop = s.hop;
-            a.t_in = (int)t_in; a.t_out = (int)t_out;
-            a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
-            a.blocks_per_stream = tab_lr[1] - tab_lr[0];
-            a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
-            a.accumulate = b == first_launch ? 0 : 1;
-            const long long slots = (long long)p->n_cu * zoom_resident(s, true);
-            if (timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
-            const bool split = timing && 2 * (long long)launches.size() - 1 <= kMidEvents;
-            int n_mid = 0;
-            hipEvent_t* mid = s.ring_mid.data() + (size_t)slot * kMidEvents;
-            int n_launches = 0;
-            for (const Launch& L : launches) {
-                a.stream0 = L.s0_lr; a.ns_lr = L.ns_lr;
-                a.stream0_c = L.s0_c; a.ns_c = L.ns_c;
-                a.f0 = (int)(-1 + 2 * L.pair0);
-                a.pair0 = (int)L.pair0;
-                a.pair_end = (int)L.pair_end;
-                const long long pairs = L.pair_end - L.pair0;
-                a.y = p->d_zoom;
-                a.yc = p->d_zoom + (size_t)(2 * pairs) * s.zoom_p;
-                // analysis grid: every resident slot once, 8 x (workgroups per XCD label), see zoom_analysis_program
-                long long per_xcd = (slots + 7) / 8;
-                if (per_xcd > (pairs + 7) / 8) per_xcd = (pairs + 7) / 8;
-                if (per_xcd < 1) per_xcd = 1;
-                a.pairs_per_wg = (int)per_xcd;
-                {   // the analysis fills every resident slot once: its workgroups take the top priority in turn (ZoomArgs)
-                    const int res = zoom_resident(s, true);
-                    a.prio_split = (p->knob_prio_young > 0 && res >= 2 && res <= 4 && 8 * per_xcd >= (long long)p->n_cu * res)
-                                       ? p->n_cu : 0;
-                    a.prio_rounds = res;
-                    // ... and the older workgroups, which still end first, take more pairs (ZoomArgs::deal_rows)
-                    a.deal_rows = 0;
-                    const long long np_xcd = (pairs + 7) / 8;      // pairs of an XCD's share (zoom_analysis_program)
-                    if (a.prio_split > 0 && p->knob_zoom_a_age > 0 && p->knob_zoom_a_age < 40 && np_xcd >= 4 * per_xcd) {
-                        const long long key = np_xcd * 4096 + per_xcd * 8 + res;
-                        const BandState::Deal* deal = nullptr;
-                        for (const auto& d : s.deals)
-                            if (d.key == key) deal = &d;
-                        if (!deal) {
-                            // pair after pair to the workgroup that would end first: round r of the `res` dispatch
-                            // rounds runs at 1 - r age of the first round's speed; ties go to the older workgroup, so
-                            // the counts never increase with l
-                            const int n_l = (int)per_xcd, per_round = n_l / res;
-                            std::vector<int> count(n_l, 0);
-                            std::vector<double> cost(n_l);
-                            for (int l = 0; l < n_l; ++l) {
-                                const int r = l / per_round < res ? l / per_round : res - 1;
-                                cost[l] = 1.0 / (1.0 - r * p->knob_zoom_a_age / 100.0);
-                            }
-                            for (long long k = 0; k < np_xcd; ++k) {
-                                int best = 0;
-                                double t_best = 1e300;
-                                for (int l = 0; l < n_l; ++l) {
-                                    const double t = (count[l] + 1) * cost[l];
-                                    if (t < t_best - 1e-9) { t_best = t; best = l; }
-                                }
-                                ++count[best];
-                            }
-                            BandState::Deal d;
-                            d.key = key;
-                            d.rows = count[n_l - 1];
-                            std::vector<int> tab(2 * (size_t)n_l);
-                            int behind = 0;
-                            for (int l = 0; l < n_l; ++l) {
-                                tab[2 * l] = behind;
-                                tab[2 * l + 1] = count[l] - d.rows;
-                                behind += tab[2 * l + 1];
-                            }
-                            if (s.deals.size() >= 8) {   // (geometries come and go: start over)
-                                HIP_TRY(hipStreamSynchronize(p->stream));
-                                for (auto& old : s.deals) (void)hipFree(old.d_tab);
-                                s.deals.clear();
-                            }
-                            HIP_TRY(hipMalloc(&d.d_tab, tab.size() * sizeof(int)));
-                            HIP_TRY(hipMemcpy(d.d_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-                            s.deals.push_back(d);
-                            deal = &s.deals.back();
-                        }
-                        a.deal_rows = deal->rows;
-                        a.deal_tab = deal->d_tab;
-                    }
-                    // ... and so does the synthesis when its streams were cut for that
-                    a.prio_split_s = (p->knob_prio_young > 0 && L.once && res_s >= 2 && res_s <= 4) ? p->n_cu : 0;
-                    a.prio_rounds_s = res_s;
-                }
-                if (n_launches == 0) {
-                    s.fill_wg = (int)((L.ns_lr + L.ns_c) * groups);
-                    s.fill_slots = p->n_cu * res_s;
-                    s.fill_wg_a = (int)(8 * per_xcd);
-                    s.fill_slots_a = (int)slots;
-                }
-                if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
-                if (!dry) s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
-                if (split) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
-                if (!dry) s.zoom->synthesis(a, groups, p->stream);
-                ++n_launches;
-            }
-            if (timing) s.ring_mid_n[slot] = n_mid;
-            if (!dry && (n_lr_total > 1 || n_c_total > 1)) {
-                if (seam_vec_ok(p, d_c, d_l, d_r, s.hop) && n_lr_total + n_c_total <= 65535)
-                    hipLaunchKernelGGL(upx_zoom_seam_add4_kernel, dim3((unsigned)((tail / 4 + 255) / 256), (unsigned)(n_lr_total + n_c_total)),
-                                       dim3(256), 0, p->stream, a, (int)n_lr_total, (int)n_c_total, (int)tail);
-                else
-                    hipLaunchKernelGGL(upx_zoom_seam_add_kernel, dim3(grid_for((n_lr_total + n_c_total) * tail)), dim3(256), 0,
-                                       p->stream, a, (int)n_lr_total, (int)n_c_total, (int)tail);
-            }
-            if (timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
-            s.last_wg = (int)((n_lr_total + n_c_total) * groups);
-            s.last_f = tab_lr[1] - tab_lr[0];
-            continue;
-        }
-        // blocks per stream: fill every resident workgroup slot once; even (whole frame pairs), at least 8 and at
-        // least K (a stream's tail must end inside the next stream).  Streams cover frames m_lo-1 .. m_hi-1.
-        const long long target_streams = max_auto_streams(p, s);
-        long long f = s.blocks_override > 0 ? s.blocks_override : (m_hi + 1 + target_streams - 1) / target_streams;
-        if (s.blocks_override <= 0 && f < p->knob_min_stream_frames) f = p->knob_min_stream_frames;
-        if (f < s.k) f = s.k;
-        f += f & 1;
-        long long n_streams = (m_hi + 1 + f - 1) / f;
-        long long n_wg = (n_streams + s.kern->g - 1) / s.kern->g;
-        // A launch that fills the machine: the first and the last workgroups run the signal-edge flavour (~12 % slower per
-        // frame; measured per workgroup, scripts/phase_prof/wgtime.hip) and the launch used to wait for them.  They get
-        // streams of edge_percent of the others' length; the others grow by what that frees (stream table, BandArgs).
-        const int G = s.kern->g;
-        const long long slots = target_streams / G;               // workgroups resident at once
-        const long long total = m_hi + 1;                         // frames -1 .. m_hi-1
-        bool uneven = false;
-        if (s.blocks_override <= 0 && p->knob_edge_percent < 100 && p->knob_edge_percent >= 50 && slots >= 8 &&
-            total >= slots * G * 16) {
-            const double share = p->knob_edge_percent / 100.0;
-            long long fu = (long long)std::ceil((double)total / ((double)G * ((double)slots - 2.0 * (1.0 - share))));
-            fu += fu & 1;
-            for (int attempt = 0; attempt < 8 && !uneven; ++attempt, fu += 2) {
-                long long fe = (long long)(share * (double)fu);
-                fe -= fe & 1;
-                if (fe < s.k + (s.k & 1) || fe < 2) break;
-                std::vector<long long> len{fe};
-                long long remaining = total - G * fe;
-                while (remaining > G * fe) {
-                    len.push_back(fu);
-                    remaining -= G * fu;
-                }
-                if (remaining > 0) {
-                    long long last = (remaining + G - 1) / G;
-                    last += last & 1;
-                    if (last < s.k + (s.k & 1)) last = s.k + (s.k & 1);
-                    len.push_back(last);
-                }
-                if ((long long)len.size() > slots) continue;        // one workgroup too many: longer streams
-                s.h_m0.assign(len.size() * G + 1, 0);
-                s.h_m0[0] = -1;
-                for (size_t w = 0; w < len.size(); ++w)
-                    for (int g = 0; g < G; ++g) s.h_m0[w * G + g + 1] = s.h_m0[w * G + g] + (int)len[w];
-                n_wg = (long long)len.size();
-                n_streams = n_wg * G;
-                f = fu;
-                uneven = true;
-            }
-        }
-        if (uneven) {
-            // the table goes to the device on the plan's stream, ordered with the launch (the host copy stays in the plan)
-            if (s.h_m0.size() > s.m0_cap) {
-                HIP_TRY(hipStreamSynchronize(p->stream));
-                if (s.d_m0) HIP_TRY(hipFree(s.d_m0));
-                s.d_m0 = nullptr;
-                s.m0_cap = 0;
-                HIP_TRY(hipMalloc(&s.d_m0, s.h_m0.size() * sizeof(int)));
-                s.m0_cap = s.h_m0.size();
-            }
-            if (s.h_m0 != s.h_m0_sent) {   // (a repeated call on the same geometry - every step of a benchmark - sends nothing)
-                HIP_TRY(hipMemcpyAsync(s.d_m0, s.h_m0.data(), s.h_m0.size() * sizeof(int), hipMemcpyHostToDevice, p->stream));
-                HIP_TRY(hipStreamSynchronize(p->stream));   // the host copy may change on the next call
-                s.h_m0_sent = s.h_m0;
-            }
-        }
-        const long long tail = (long long)(s.k - 1) * s.hop;
-        const size_t seam_need = (size_t)n_wg * s.kern->g * 3 * tail;
-        if (seam_need > p->seam_floats) {
-            HIP_TRY(hipStreamSynchronize(p->stream));
-            if (p->d_seam) HIP_TRY(hipFree(p->d_seam));
-            p->d_seam = nullptr;
-            HIP_TRY(hipMalloc(&p->d_seam, seam_need * sizeof(float)));
-            p->seam_floats = seam_need;
-        }
-        upx::BandArgs a;
-        a.in = reinterpret_cast<const upx::cf*>(d_stereo);
-        a.out_c = d_c; a.out_l = d_l; a.out_r = d_r;
-        a.w_a = s.d_wa; a.w_s = s.d_ws; a.gain = s.d_gain; a.tw = s.d_tw;
-        a.n_gain = s.n_gain; a.gain_stride = s.n / 2 + 1;
-        a.t_in = (int)t_in; a.t_out = (int)t_out;
-        a.j_lo = 0; a.j_hi = (int)j_hi; a.m_lo = 0; a.m_hi = (int)m_hi;
-        a.blocks_per_stream = (int)f;
-        a.stream_m0 = uneven ? s.d_m0 : nullptr;
-        a.accumulate = b == first_launch ? 0 : 1;
-        a.seam = p->d_seam;
-        // one-wave workgroups that fill the machine: the first `SIMDs` of them are the older wave of their SIMD
-        // (BandArgs::prio_split)
-        // ... and two-wave workgroups (N = 2048: four per CU) run at four speeds by dispatch round; the rounds take the top
-        // priority in turn (prio_split < 0: workgroups per round)
-        a.prio_split = 0;
-        if (p->knob_prio_young > 0 && p->knob_prio_young < 4) {
-            if (s.kern->wg == 64 && n_wg > 4LL * p->n_cu) a.prio_split = 4 * p->n_cu;
-            else if (s.kern->wg == 128 && n_wg > 2LL * p->n_cu) a.prio_split = -p->n_cu;
-        }
-        a.prio_young = p->knob_prio_young;
-        // stream seams inside the launch (seam_epilogue; experiment, default off: the agent-scope release / acquire it needs costs more
-        // than the launch it saves - c1 0.030 -> 0.070 ms, C3 fused launches +40 %) or in a launch of their own: UPX_SEAM_INKERNEL = 1 always, 2
-        // when the launch does not fill the chip - a short signal, where the seam launch is a sixth of the step -, 0 never
-        const bool seam_inside = n_streams > 1 && p->d_pair_cnt && n_wg <= (long long)p->pair_cnt_n &&
-                                 (p->knob_seam_inkernel == 1 || (p->knob_seam_inkernel == 2 && n_wg <= slots));
-        a.pair_cnt = seam_inside ? p->d_pair_cnt : nullptr;
-        a.n_streams = (int)n_streams;
-        s.last_wg = (int)n_wg;
-        s.last_f = (int)f;
-        s.fill_wg = (int)n_wg;
-        s.fill_slots = (int)slots;
-        s.fill_wg_a = s.fill_slots_a = 0;
-        if (timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
-        if (!dry) s.kern->launch(a, (int)n_wg, p->stream);
-        if (!dry && n_streams > 1 && !seam_inside) {
-            if (seam_vec_ok(p, d_c, d_l, d_r, s.hop) && n_streams <= 65535)
-                hipLaunchKernelGGL(upx_stream_seam_add4_kernel, dim3((unsigned)((tail / 4 + 255) / 256), (unsigned)n_streams), dim3(256), 0,
-                                   p->stream, a, (int)n_streams, (int)tail, s.hop);
-            else
-                hipLaunchKernelGGL(upx_stream_seam_add_kernel, dim3(grid_for(n_streams * tail)), dim3(256), 0, p->stream, a,
-                                   (int)n_streams, (int)tail, s.hop);
-        }
-        if (timing) HIP_TRY(hipEventRecord(s.ev1, p->stream));
+        if (rc != UPX_OK) break;
     }
+    if (dry) {
+        kept.restore(p);
+        return rc;
+    }
+    if (rc != UPX_OK) return rc;
     HIP_TRY(hipGetLastError());
-    if (dry) return UPX_OK;
-    p->timed_once = p->timing;
-    if (p->timing) {
-        for (auto& s : p->bands) s.ring_used[slot] = s.last_wg > 0;
+    if (c.timing) {
+        p->timed_once = true;
+        for (auto& s : p->bands) {
+            s.ring_used[c.slot] = s.last_wg > 0;
+            s.timed_wg = s.last_wg;
+        }
         p->timed_calls += 1;
     }
     return UPX_OK;
@@ -1422,9 +1642,11 @@ int upx_plan_reserve(upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out) 
         HIP_TRY(hipMalloc(&tmp, (size_t)n * 5 * sizeof(float)));
         hipError_t e = hipMemsetAsync(tmp, 0, (size_t)n * 2 * sizeof(float), p->stream);
         const bool timing = p->timing;
-        p->timing = false;
+        const Reports kept(p);           // the warm-up is not a call of the caller's: it leaves no trace in the reports ...
+        p->timing = false;               // ... and none in the event rings (timed_once / timed_calls are untouched by untimed calls)
         int rc = e == hipSuccess ? upx_process_device(p, tmp, n, n, tmp + 2 * n, tmp + 3 * n, tmp + 4 * n, n) : UPX_ERR_HIP;
         p->timing = timing;
+        kept.restore(p);
         (void)hipStreamSynchronize(p->stream);
         (void)hipFree(tmp);
         if (rc != UPX_OK) return rc;
@@ -1591,7 +1813,7 @@ int run_items(upx_plan* p, const std::vector<PipeItem>& items) {
     }
     const size_t plane = p->pipe_out_floats / 3;
 #if defined(UPX_TEST_HOOKS)   // never in the product library: a test build fails the download of this item
-    const char* inject = std::getenv("UPX_TEST_FAIL_DOWNLOAD");
+    const char* inject = knob("UPX_TEST_FAIL_DOWNLOAD");
     const int64_t inject_at = inject ? std::atoll(inject) : -1;
 #else
     const int64_t inject_at = -1;
@@ -1747,7 +1969,7 @@ int upx_plan_band_times_ms(upx_plan* p, float* ms, int n_bands) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     for (int b = 0; b < n_bands; ++b) {
         ms[b] = 0.f;
-        if (p->bands[b].last_wg > 0) HIP_TRY(hipEventElapsedTime(&ms[b], p->bands[b].ev0, p->bands[b].ev1));
+        if (p->bands[b].timed_wg > 0) HIP_TRY(hipEventElapsedTime(&ms[b], p->bands[b].ev0, p->bands[b].ev1));
     }
     return UPX_OK;
 }
@@ -2371,9 +2593,20 @@ int upx_comm_create(upx_comm** out, upx_plan* plan, int rank, int n_ranks, const
     c->plan = plan;
     c->rank = rank;
     c->n_ranks = n_ranks;
-    if (const char* e = std::getenv("UPX_COMM_TIMEOUT")) c->timeout_s = std::atof(e);
-    else if (const char* e2 = std::getenv("UPX_RDZV_TIMEOUT")) c->timeout_s = std::atof(e2);
-    if (!(c->timeout_s > 0.0)) c->timeout_s = 600.0;
+    // UPX_COMM_TIMEOUT, else UPX_RDZV_TIMEOUT, else 600 s - parsed exactly like sharding.comm_timeout (a value that is not a
+    // positive number falls through to the next variable), so that the Python watchdog and this wait agree
+    c->timeout_s = 600.0;
+    for (const char* name : {"UPX_COMM_TIMEOUT", "UPX_RDZV_TIMEOUT"}) {
+        const char* e = std::getenv(name);
+        if (!e || !*e) continue;
+        char* end = nullptr;
+        const double v = std::strtod(e, &end);
+        while (end && (*end == ' ' || *end == '\t' || *end == '\n')) ++end;
+        if (end && end != e && *end == 0 && v > 0.0 && std::isfinite(v)) {
+            c->timeout_s = v;
+            break;
+        }
+    }
     // (blocking: every rank must arrive - the callers vote over their process group BEFORE this call and keep a watchdog
     // on it, sharding.RcclSeam)
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
@@ -2381,7 +2614,22 @@ int upx_comm_create(upx_comm** out, upx_plan* plan, int rank, int n_ranks, const
         delete c;
         return fail(UPX_ERR_RCCL, "ncclCommInitRank(rank %d of %d): %s", rank, n_ranks, g_rccl.GetErrorString(r));
     }
-    if (hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess) c->ev_done = nullptr;
+    // upx_comm_wait polls these two; without them the wait would be an unbounded hipStreamSynchronize again, so a
+    // communicator that cannot have them is not handed out (one retry: event creation fails transiently at most)
+    for (hipEvent_t* ev : {&c->ev_start, &c->ev_done}) {
+        hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (e != hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            *ev = nullptr;
+            const int rc = fail(UPX_ERR_HIP, "upx_comm_create: hipEventCreate: %s", hipGetErrorString(e));
+            const std::string msg = g_err;
+            if (g_rccl.CommAbort) (void)g_rccl.CommAbort(c->comm);   // (a destroy could wait for peers that go on to use theirs)
+            c->comm = nullptr;
+            upx_comm_destroy(c);
+            g_err = msg;
+            return rc;
+        }
+    }
     *out = c;
     return UPX_OK;
 }
@@ -2402,21 +2650,19 @@ int upx_comm_abort(upx_comm* c) {
 }
 
 // Waits until the last queued seam exchange has run on the plan's stream.  timeout_s < 0: the communicator's default
-// (UPX_COMM_TIMEOUT / UPX_RDZV_TIMEOUT / 600 s).  If the time runs out - a peer that never entered the all-reduce - or
-// RCCL reports an asynchronous error, the communicator is ABORTED and an error returned, instead of a
-// hipStreamSynchronize that never comes back.
+// (UPX_COMM_TIMEOUT / UPX_RDZV_TIMEOUT / 600 s).  The limit applies to the PEERS: its clock starts when the stream has
+// reached the all-reduce (ev_start), not at the entry of this call - the shard's own kernels queued ahead of the exchange get
+// the same limit of their own.  If either runs out - a peer that never entered the all-reduce - or RCCL reports an
+// asynchronous error, the communicator is ABORTED and an error returned, instead of a hipStreamSynchronize that never comes
+// back.  (Multi-rank abort has only ever run on a one-rank communicator: one-GPU boxes.)
 int upx_comm_wait(upx_comm* c, double timeout_s) {
     if (!c) return fail(UPX_ERR_INVALID, "upx_comm_wait: NULL");
     if (c->aborted) return fail(UPX_ERR_RCCL, "the communicator has been aborted");
     if (!c->pending) return UPX_OK;
     HIP_TRY(hipSetDevice(c->plan->device));
-    if (!c->ev_done) {   // (no event: plain wait)
-        HIP_TRY(hipStreamSynchronize(c->plan->stream));
-        c->pending = false;
-        return UPX_OK;
-    }
     const double limit = timeout_s >= 0.0 ? timeout_s : c->timeout_s;
-    const double t0 = wall_ms();
+    double t0 = wall_ms();
+    bool reached = false;            // the stream has reached the all-reduce
     long long spins = 0;
     for (;;) {
         const hipError_t q = hipEventQuery(c->ev_done);
@@ -2425,6 +2671,10 @@ int upx_comm_wait(upx_comm* c, double timeout_s) {
             return UPX_OK;
         }
         if (q != hipErrorNotReady) return fail(UPX_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+        if (!reached && hipEventQuery(c->ev_start) == hipSuccess) {
+            reached = true;
+            t0 = wall_ms();
+        }
         const double waited = (wall_ms() - t0) * 1e-3;
         if ((++spins & 255) == 0 && g_rccl.CommGetAsyncError && c->comm) {
             ncclResult_t async = ncclSuccess;
@@ -2436,7 +2686,10 @@ int upx_comm_wait(upx_comm* c, double timeout_s) {
         }
         if (waited > limit) {
             (void)upx_comm_abort(c);
-            return fail(UPX_ERR_RCCL, "rank %d: the seam all-reduce did not finish within %.1f s (a peer never arrived); "
+            if (reached)
+                return fail(UPX_ERR_RCCL, "rank %d: the seam all-reduce did not finish within %.1f s (a peer never arrived); "
+                                          "communicator aborted", c->rank, limit);
+            return fail(UPX_ERR_RCCL, "rank %d: the stream did not finish within %.1f s what was queued ahead of the seam all-reduce; "
                                       "communicator aborted", c->rank, limit);
         }
         if (waited < 2e-3) continue;                       // a healthy exchange takes tens of microseconds: spin first
@@ -2448,6 +2701,7 @@ void upx_comm_destroy(upx_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->plan->device);
     if (c->d_seam) (void)hipFree(c->d_seam);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->comm && !c->aborted && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     delete c;
@@ -2473,6 +2727,7 @@ int seam_exchange_impl(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t 
     if (pack)
         hipLaunchKernelGGL(upx_seam_pack_kernel, dim3(grid_for(spill)), dim3(256), 0, p->stream,
                            c->d_seam + row * my_row, d_c, d_l, d_r, (long long)own_len, (long long)spill, (long long)spill);
+    HIP_TRY(hipEventRecord(c->ev_start, p->stream));
     NCCL_TRY(g_rccl.AllReduce(c->d_seam, c->d_seam, (size_t)total, ncclFloat32, ncclSum, c->comm, p->stream));
     if (add_row >= 0 && add_len > 0) {
         const float* prev = c->d_seam + row * add_row;
@@ -2480,7 +2735,7 @@ int seam_exchange_impl(upx_comm* c, float* d_c, float* d_l, float* d_r, int64_t 
                            prev + spill, prev + 2 * spill, (long long)add_len);
     }
     HIP_TRY(hipGetLastError());
-    if (c->ev_done) HIP_TRY(hipEventRecord(c->ev_done, p->stream));
+    HIP_TRY(hipEventRecord(c->ev_done, p->stream));
     c->pending = true;
     return UPX_OK;
 }

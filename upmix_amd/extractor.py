@@ -402,6 +402,23 @@ class DevicePlan:
             pass
 
 
+def plan_kernel_names(extractors: Sequence["MultiBandExtractorAccu"]) -> List[str]:
+    """
+    The kernel(s) the library would select for every band of this list ("analysis|synthesis" for a band-limited group),
+    without a GPU (upx_plan_kernel_names: the selection half of upx_plan_create).
+    """
+    lib = _lib.load()
+    blocks = np.asarray([int(b.block_size) for b in extractors], dtype=np.int32)
+    hops = np.asarray([int(b.hop_size) for b in extractors], dtype=np.int32)
+    wa = np.ascontiguousarray(np.concatenate([np.asarray(b.analysis_window, dtype=np.float32) for b in extractors]))
+    ws = np.ascontiguousarray(np.concatenate([np.asarray(b.synthesis_window, dtype=np.float32) for b in extractors]))
+    gains = np.ascontiguousarray(np.concatenate([b.gain_vector().astype(np.float32) for b in extractors]))
+    buf = C.create_string_buffer(256 * max(1, len(extractors)))
+    _lib.check(lib.upx_plan_kernel_names(len(extractors), blocks.ctypes.data_as(_lib.i32p), hops.ctypes.data_as(_lib.i32p),
+                                         _f32p(wa), _f32p(ws), _f32p(gains), buf, len(buf)))
+    return buf.value.decode().splitlines()
+
+
 class MultiBandExtractorAccu:
     """
     Per-band extractor with the constructor and attributes of the reference class
@@ -431,6 +448,21 @@ class MultiBandExtractorAccu:
         self._accum = [np.zeros(block_size, dtype=np.float32) for _ in range(3)]
         self._plan: Optional[DevicePlan] = None
         self._streaming = False    # the accumulators are on the device
+
+    # what _band_signature() is made of: assigning any of them drops the memoised signature, so the next drop-in call keys
+    # (and, if need be, builds) the plan for the new values
+    _SIGNATURE_FIELDS = frozenset(("block_size", "hop_size", "sr", "f_low", "f_high", "xover_mode", "xover_width_low_hz",
+                                   "xover_width_high_hz", "analysis_window", "synthesis_window"))
+
+    def __setattr__(self, name, value):
+        if name in MultiBandExtractorAccu._SIGNATURE_FIELDS:
+            self.__dict__.pop("_signature", None)
+            if self.__dict__.get("_plan") is not None:
+                self.close()                       # the one-band plan of process_all_blocks was built from the old values
+            if name in ("analysis_window", "synthesis_window") and isinstance(value, np.ndarray):
+                value = value.view()
+                value.flags.writeable = False      # an in-place edit would leave a stale plan behind silently: make it raise
+        object.__setattr__(self, name, value)
 
     def close(self) -> None:
         """Release the device state this extractor owns (its one-band plan with the streaming ring)."""
@@ -535,11 +567,33 @@ _PLAN_CACHE_SIZE = 4
 
 
 def _band_signature(b: "MultiBandExtractorAccu") -> tuple:
-    """Everything that determines a band's device state (ids of Python objects can be recycled, values cannot)."""
-    return (int(b.block_size), int(b.hop_size), float(b.sr), float(b.f_low), float(b.f_high), str(b.xover_mode),
-            float(b.xover_width_low_hz), float(b.xover_width_high_hz),
-            hash(np.asarray(b.analysis_window, dtype=np.float32).tobytes()),
-            hash(np.asarray(b.synthesis_window, dtype=np.float32).tobytes()))
+    """
+    Everything that determines a band's device state (ids of Python objects can be recycled, values cannot).  Hashing both
+    windows costs 0.17 ms (C3 plan) to 0.7 ms (default plan: 1.2 MB) per call, so the signature is kept on the extractor and
+    dropped whenever one of the attributes it is made of is assigned (MultiBandExtractorAccu.__setattr__); the window arrays
+    are handed out read-only so that an in-place edit cannot go unnoticed - `ext.analysis_window[:] = w` raises, `ext.
+    analysis_window = w` (what the reference's own code does, center_extraction.py:255-256) re-keys the plan.
+    """
+    sig = b.__dict__.get("_signature")
+    if sig is None:
+        sig = (int(b.block_size), int(b.hop_size), float(b.sr), float(b.f_low), float(b.f_high), str(b.xover_mode),
+               float(b.xover_width_low_hz), float(b.xover_width_high_hz),
+               hash(np.asarray(b.analysis_window, dtype=np.float32).tobytes()),
+               hash(np.asarray(b.synthesis_window, dtype=np.float32).tobytes()))
+        b.__dict__["_signature"] = sig
+    return sig
+
+
+def _env_knobs() -> tuple:
+    """
+    The UPX_* environment as a hashable key (the library reads its tuning knobs when a plan is created: a plan made under
+    other settings is another plan).  os.environ keeps the raw bytes in a dict; filtering that costs ~2 us where decoding
+    every variable through os.environ.items() cost 15-30.
+    """
+    data = getattr(os.environ, "_data", None)
+    if isinstance(data, dict):
+        return tuple(sorted(kv for kv in data.items() if kv[0].startswith(b"UPX_")))
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("UPX_")))
 
 
 @contextlib.contextmanager
@@ -549,9 +603,7 @@ def _checked_out_plan(band_extractors: Sequence[MultiBandExtractorAccu], device:
     look-up, creation and eviction happen under one lock, and a plan that some thread is using is never evicted
     (the cache may exceed its size for that long).
     """
-    # (the library reads its UPX_* tuning knobs when a plan is created: a plan made under other settings is another plan)
-    knobs = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("UPX_")))
-    key = (tuple(_band_signature(b) for b in band_extractors), device, knobs)
+    key = (tuple(_band_signature(b) for b in band_extractors), device, _env_knobs())
     with _PLAN_CACHE_LOCK:
         plan = _PLAN_CACHE.pop(key, None)
         if plan is None:

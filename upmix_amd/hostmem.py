@@ -43,6 +43,8 @@ class _Lease:
 class PinnedPool:
     """Blocks of page-locked memory of one device plan's process, recycled by capacity."""
 
+    _ASKED_MAX = 256         # capacities remembered for lazy pinning (oldest forgotten first)
+
     def __init__(self, limit_bytes: int):
         self.limit = int(limit_bytes)
         self._free: Dict[int, List[int]] = {}
@@ -87,7 +89,12 @@ class PinnedPool:
             ptr = stack.pop() if stack else None
             if ptr is None and lazy:
                 first = self._asked.setdefault(cap, lazy)
+                while len(self._asked) > self._ASKED_MAX:        # sizes that differ on every call (a directory of tracks)
+                    self._asked.pop(next(iter(self._asked)))     # must not grow this for ever: the oldest request goes
                 if first == lazy:
+                    # a plan is alive again (this call comes from one): the sweeper of an earlier idle period must stop
+                    self._plan_handle = plan_handle
+                    self.plans_live = True
                     return np.empty(nbytes, dtype=np.uint8)
             if ptr is None:
                 # make room by releasing idle blocks of other sizes before giving up
@@ -141,6 +148,8 @@ class PinnedPool:
             time.sleep(0.25)
             if sys.is_finalizing():
                 return
+            if not self._returned and not self.plans_live and not self.closed:
+                continue               # nothing came back since the last look: no lock, no runtime call (hipHostFree synchronises)
             with self._lock:
                 if self.plans_live or self.closed:
                     self._sweeper = None
@@ -170,6 +179,24 @@ class PinnedPool:
     def close(self) -> None:
         with self._lock:
             self.closed = True
+
+    def pinned_bytes(self) -> int:
+        """Bytes this pool holds page-locked right now (idle + leased blocks)."""
+        with self._lock:
+            return self._held
+
+    def reset_for_tests(self, plan_handle=None) -> dict:
+        """
+        The pool as a fresh process finds it: idle blocks unpinned, the lazy-pinning memory ("which call first asked for
+        this size") forgotten.  Blocks still leased to live arrays stay theirs.  Returns {"held": bytes still pinned
+        (= leased), "idle_released": bytes unpinned}.  For tests whose assertions depend on which call is the first of
+        its size - they must not reach into the pool's private fields.
+        """
+        with self._lock:
+            before = self._held
+            self._release_idle(plan_handle)
+            self._asked.clear()
+            return {"held": self._held, "idle_released": before - self._held}
 
 
 def default_limit(env=os.environ, meminfo: str = "/proc/meminfo") -> int:

@@ -186,20 +186,32 @@ class _Watchdog:
     Ends the process if the body does not return in time.  For the one blocking collective call that has no error path of
     its own (ncclCommInitRank: a rank whose peer never arrives waits inside it for ever; ctypes has released the GIL, so
     the timer thread runs).  The main thread is inside a C call that will never return, so no exception can reach it: the
-    watchdog writes the reason to stderr and terminates the process with SIGTERM's default action (status 143; launchers
-    report it as a failed rank) - a fresh process is the only restart.
+    watchdog writes the reason to stderr and sends the process SIGTERM (default action: status 143; launchers report it as a
+    failed rank).  An embedding application may have installed a Python SIGTERM handler: Python runs handlers on the main
+    thread only - the thread that is blocked -, so such a handler never runs and the process would stay; after `grace`
+    seconds the watchdog therefore ends the process directly (exit status 143) whatever handlers exist.  A fresh process is the only
+    restart, never a re-exec.
     """
 
-    def __init__(self, seconds: float, what: str):
+    GRACE_S = 3.0
+
+    def __init__(self, seconds: float, what: str, grace: Optional[float] = None):
         self.seconds, self.what, self._timer = float(seconds), what, None
+        self.grace = self.GRACE_S if grace is None else float(grace)
 
     def _fire(self):
         import os
         import signal
         import sys
+        import time
         print(f"[upmix_amd] {self.what} did not return within {self.seconds:g} s: a peer never arrived; terminating",
               file=sys.stderr, flush=True)
         os.kill(os.getpid(), signal.SIGTERM)
+        # still here: SIGTERM is handled (or ignored) by the host application and its handler cannot run, see above
+        time.sleep(max(self.grace, 0.0))
+        print(f"[upmix_amd] SIGTERM did not end the process within {self.grace:g} s (a handler is installed); exit status 143",
+              file=sys.stderr, flush=True)
+        os._exit(143)
 
     def __enter__(self):
         import threading
