@@ -191,6 +191,7 @@ int upx_plan_band_times_calls_ms(upx_plan* plan, float* ms, int n_bands, int n_c
    or the band's only kernel. */
 int upx_plan_band_phase_times_sum_ms(upx_plan* plan, float* ms_analysis, float* ms_synthesis, int n_bands, int n_calls);
 int upx_plan_band_phase_kernel_name(upx_plan* plan, int band, int phase, char* name, size_t n);
+
 /* Kernel symbol name / launch geometry of a band (for profiles and DESIGN.md). */
 int upx_plan_band_info(upx_plan* plan, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,
                        int32_t* blocks_per_stream);

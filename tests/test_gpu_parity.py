@@ -556,7 +556,7 @@ def test_a_poisoned_environment_changes_neither_kernels_nor_bits(ux, orc, monkey
     monkeypatch.setenv("UPX_FORCE_UNFUSED", "1")
     bands = gpu_chain(ux, edges, 48000, 8192, 32)
     plan = ux.DevicePlan(bands)
-    assert all("big" in plan.band_kernel_name(i) for i in range(len(bands)))
+    assert all("unfused" in plan.band_kernel_name(i) for i in range(len(bands)))
     forced = plan.process(x)
     plan.close()
     for a, b in zip(clean[2], forced):

@@ -112,6 +112,29 @@ UPX_HD cf twice_minus(cf p, cf t) {   // (the inline constant is the low half: b
     asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(p), "v"(t));
     return r;
 }
+// The pair in ONE asm statement (UPX_BFLY_ASM): sum = c + a b, diff = 2 c - sum.  The backend treats every inline asm that
+// defines a VGPR as a possible partial-register writer ("assume inline asm has dst forwarding hazard") and puts an
+// `s_nop 0` in front of a consumer that follows it directly - 59 of the 88 s_nop of the N = 256 interior loop sat between
+// cfma and its twice_minus (round 6 hazard audit, profiles/r06_hazard_audit.txt).  Inside one statement nothing is inserted;
+// v_pk_fma_f32 writes whole registers, and cfma's own second instruction already consumes the first one's result back to back.
+#if !defined(UPX_BFLY_ASM)
+#define UPX_BFLY_ASM 0
+#endif
+UPX_HD void bfly(cf a, cf b, cf c, cf& sum, cf& diff) {
+#if UPX_BFLY_ASM
+    cf t, d;
+    asm("v_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %4, 2.0, %0 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+        : "=&v"(t), "=&v"(d)
+        : "v"(a), "v"(b), "v"(c));
+    sum = t;
+    diff = d;
+#else
+    sum = cfma(a, b, c);
+    diff = twice_minus(c, sum);
+#endif
+}
 // the same with a compile-time constant b: it lives in a scalar register pair (one scalar source per instruction),
 // not in two vector registers that the allocator would have to keep or rebuild
 UPX_HD cf cmul_k(cf a, cf b) {
@@ -130,7 +153,24 @@ UPX_HD cf cfma_k(cf a, cf b, cf c) {
         : "v"(a), "s"(b), "v"(c));
     return t;
 }
+UPX_HD void bfly_k(cf a, cf b, cf c, cf& sum, cf& diff) {
+#if UPX_BFLY_ASM
+    cf t, d;
+    asm("v_pk_fma_f32 %0, %2, %3, %4 op_sel:[0,0,0] op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %4, 2.0, %0 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+        : "=&v"(t), "=&v"(d)
+        : "v"(a), "s"(b), "v"(c));
+    sum = t;
+    diff = d;
 #else
+    sum = cfma_k(a, b, c);
+    diff = twice_minus(c, sum);
+#endif
+}
+#else
+UPX_HD void bfly(cf a, cf b, cf c, cf& sum, cf& diff);
+UPX_HD void bfly_k(cf a, cf b, cf c, cf& sum, cf& diff);
 UPX_HD cf cmul_k(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 UPX_HD cf cfma_k(cf a, cf b, cf c) {
     return mk(__builtin_fmaf(-a.y, b.y, __builtin_fmaf(a.x, b.x, c.x)), __builtin_fmaf(a.y, b.x, __builtin_fmaf(a.x, b.y, c.y)));
@@ -139,6 +179,8 @@ UPX_HD cf cfma(cf a, cf b, cf c) {
     return mk(__builtin_fmaf(-a.y, b.y, __builtin_fmaf(a.x, b.x, c.x)), __builtin_fmaf(a.y, b.x, __builtin_fmaf(a.x, b.y, c.y)));
 }
 UPX_HD cf twice_minus(cf p, cf t) { return mk(__builtin_fmaf(2.0f, p.x, -t.x), __builtin_fmaf(2.0f, p.y, -t.y)); }
+UPX_HD void bfly(cf a, cf b, cf c, cf& sum, cf& diff) { sum = cfma(a, b, c); diff = twice_minus(c, sum); }
+UPX_HD void bfly_k(cf a, cf b, cf c, cf& sum, cf& diff) { sum = cfma_k(a, b, c); diff = twice_minus(c, sum); }
 UPX_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 UPX_HD cf add_mi(cf a, cf b) { return mk(a.x + b.y, a.y - b.x); }
 UPX_HD cf sub_mi(cf a, cf b) { return mk(a.x - b.y, a.y + b.x); }
@@ -359,11 +401,13 @@ UPX_HD void dft4_tw(cf& a0, cf& a1, cf& a2, cf& a3, cf w0, cf w1, cf w2, cf w3) 
         t0 = add_mi(p0, a2);
         t1 = sub_mi(p0, a2);
     } else {
-        t0 = KONST ? cfma_k(a2, w2, p0) : cfma(a2, w2, p0);
-        t1 = twice_minus(p0, t0);
+        if constexpr (KONST) bfly_k(a2, w2, p0, t0, t1);
+        else bfly(a2, w2, p0, t0, t1);
     }
     const cf p1 = KONST ? cmul_k(a1, w1) : cmul(a1, w1);
-    const cf t2 = KONST ? cfma_k(a3, w3, p1) : cfma(a3, w3, p1), d = twice_minus(p1, t2);
+    cf t2, d;
+    if constexpr (KONST) bfly_k(a3, w3, p1, t2, d);
+    else bfly(a3, w3, p1, t2, d);
     a0 = t0 + t2;
     a2 = t0 - t2;
     a1 = add_mi(t1, d);
@@ -482,8 +526,9 @@ struct Dft<2> {
     static UPX_HD void run(cf* v) { dft2(v[0], v[1]); }
     static UPX_HD void run_tw(cf* v, const cf* w) {
 #if UPX_FMA_BUTTERFLY
-        const cf t = cfma(v[1], w[1], v[0]);
-        v[1] = twice_minus(v[0], t);
+        cf t, d;
+        bfly(v[1], w[1], v[0], t, d);
+        v[1] = d;
         v[0] = t;
 #else
         v[1] = cmul(v[1], w[1]);
@@ -519,8 +564,8 @@ struct Dft<8> {
         v[0] = e0 + o0; v[4] = e0 - o0;
         v[2] = add_mi(e2, o2); v[6] = sub_mi(e2, o2);   // o2 * (-i)
 #if UPX_FMA_BUTTERFLY
-        v[1] = cfma_k(o1, mk(kSqrtHalf, -kSqrtHalf), e1); v[5] = twice_minus(e1, v[1]);
-        v[3] = cfma_k(o3, mk(-kSqrtHalf, -kSqrtHalf), e3); v[7] = twice_minus(e3, v[3]);
+        bfly_k(o1, mk(kSqrtHalf, -kSqrtHalf), e1, v[1], v[5]);
+        bfly_k(o3, mk(-kSqrtHalf, -kSqrtHalf), e3, v[3], v[7]);
 #else
         o1 = mul_w8_1(o1);
         o3 = mul_w8_3(o3);

@@ -153,6 +153,30 @@ __device__ __forceinline__ void upx_absmax_body(const float* x, long long n, uns
     }
 }
 
+// max |x| of 32-bit PCM as an integer (|INT_MIN| = 2^31 fits the unsigned word).  main.py:53 takes the input peak over the
+// float64 samples soundfile.read returns (x / 2^31): for 16- and 24-bit files the float32 copy the kernels transform holds
+// those exactly and upx_absmax_kernel on it is the same number; for 32-bit files it does not - the peak is taken on the
+// integers and divided on the host, so that the one global scale of main.py:85-97 is the reference's to the last bit.
+__global__ void upx_absmax_i32_kernel(const int* x, long long n, unsigned int* result) {
+    __shared__ unsigned int part[4];
+    unsigned int m = 0u;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int v = x[i];
+        const unsigned int a = v < 0 ? 0u - (unsigned int)v : (unsigned int)v;
+        m = a > m ? a : m;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int q = (unsigned int)__shfl_xor((int)m, o);
+        m = q > m ? q : m;
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = part[w] > m ? part[w] : m;
+        if (m) atomicMax(result, m);
+    }
+}
+
 __global__ void upx_scale_kernel(float* x, long long n, float s) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         x[i] *= s;
@@ -304,6 +328,24 @@ const char* knob(const char* name) {
     return std::getenv(name);
 }
 
+double wall_ms() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+// UPX_PLAN_TIMING=1 (with UPX_TUNING=1): upx_plan_create prints where its time goes (scripts/plan_create_breakdown.py)
+struct PlanClock {
+    bool on;
+    double t0, last;
+    PlanClock() : on(knob("UPX_PLAN_TIMING") != nullptr), t0(wall_ms()), last(t0) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const double now = wall_ms();
+        std::fprintf(stderr, "[upx_plan_create] %-34s %8.3f ms  (at %8.3f)\n", what, now - last, now - t0);
+        last = now;
+    }
+};
+
 // (log2 N, K, variant) -> fused kernel; the tables live in upx_reg_fused*.hip.
 const KernelEntry* find_kernel(int log2n, int k, int variant) {
 #if defined(UPX_EXPERIMENTS)
@@ -446,6 +488,7 @@ struct upx_plan {
     float* d_wav_side[2] = {nullptr, nullptr};
     size_t wav_side_floats = 0;
     unsigned int* d_wav_peaks = nullptr;
+    double wav_in_peak = 0.0;               // the input peak the last seal reported (32-bit PCM: taken on the integers)
     bool wav_peaks_pending_head = false;    // multi-rank: chunk 0's plane peaks wait for the RCCL seam
     int64_t wav_head_own = 0;
     // between upx_wav_shard_open and _seal: the chunk list, frames fed / decoded, the next chunk to run
@@ -810,8 +853,14 @@ int plan_select(upx_plan* p, int n_bands, const int32_t* block_size, const int32
 // Upload: what the selected kernels read on the device - windows, twiddles, ramp seeds, gain tables - and the plan's
 // buffers (timing events, scratch of the unfused and band-limited paths, stream seam buffer)
 int plan_upload(upx_plan* p, const float* w_analysis, const float* w_synthesis, const std::vector<size_t>& band_win_off,
-                const std::vector<std::vector<float>>& gain_tables) {
+                const std::vector<std::vector<float>>& gain_tables, PlanClock* clock) {
     const int n_bands = (int)p->bands.size();
+    double t_events = 0.0, t_prepare = 0.0, t_tables = 0.0, t_mark = wall_ms();
+    auto mark = [&t_mark](double& acc) {
+        const double now = wall_ms();
+        acc += now - t_mark;
+        t_mark = now;
+    };
     for (int b = 0; b < n_bands; ++b) {
         BandState& s = p->bands[b];
         const size_t off_w = band_win_off[b];
@@ -824,6 +873,7 @@ int plan_upload(upx_plan* p, const float* w_analysis, const float* w_synthesis, 
         }
         s.ev0 = s.ring0[0];
         s.ev1 = s.ring1[0];
+        mark(t_events);
         if (s.group_size == 0) continue;   // carried by its group leader's launch
         // the dynamic LDS of the group's kernels
         if (s.zoom && s.zoom_a != s.zoom)
@@ -831,11 +881,13 @@ int plan_upload(upx_plan* p, const float* w_analysis, const float* w_synthesis, 
                 return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
         if (int e = s.zoom ? s.zoom->prepare() : (s.kern ? s.kern->prepare() : s.big->prepare()))
             return fail(UPX_ERR_HIP, "hipFuncSetAttribute(STFT %d): %s", s.n, hipGetErrorString((hipError_t)e));
+        mark(t_prepare);
         if (s.zoom) {
             s.ring_mid.assign((size_t)kTimingSlots * kMidEvents, nullptr);
             s.ring_mid_n.assign(kTimingSlots, 0);
             for (auto& e : s.ring_mid) HIP_TRY(hipEventCreate(&e));
         }
+        mark(t_events);
         std::vector<float> ws(s.n);
         for (int i = 0; i < s.n; ++i) ws[i] = w_synthesis[off_w + i] / (float)s.n;   // exact: N is a power of two
         HIP_TRY(hipMalloc(&s.d_wa, s.n * sizeof(float)));
@@ -885,6 +937,12 @@ int plan_upload(upx_plan* p, const float* w_analysis, const float* w_synthesis, 
         const std::vector<float>& table = gain_tables[b];
         HIP_TRY(hipMalloc(&s.d_gain, table.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(s.d_gain, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice));
+        mark(t_tables);
+    }
+    if (clock && clock->on) {
+        std::fprintf(stderr, "[upx_plan_create]   events %.3f ms, hipFuncSetAttribute (code objects) %.3f ms, tables (malloc + memcpy) %.3f ms\n",
+                     t_events, t_prepare, t_tables);
+        clock->lap("plan_upload: per band");
     }
     if (p->scratch_cf) HIP_TRY(hipMalloc(&p->d_scratch, p->scratch_cf * sizeof(upx::cf)));
     if (p->zoom_cf) HIP_TRY(hipMalloc(&p->d_zoom, p->zoom_cf * sizeof(upx::cf)));
@@ -918,10 +976,13 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
                     const float* w_analysis, const float* w_synthesis, const float* gain) {
     if (!out) return fail(UPX_ERR_INVALID, "upx_plan_create: NULL argument or n_bands < 1");
     if (int rc = check_bands("upx_plan_create", n_bands, block_size, hop, w_analysis, w_synthesis, gain)) return rc;
+    PlanClock clock;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) return fail(UPX_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n_dev) return fail(UPX_ERR_INVALID, "device %d out of range (0..%d)", device, n_dev - 1);
+    clock.lap("hipGetDeviceCount");
     HIP_TRY(hipSetDevice(device));
+    clock.lap("hipSetDevice");
     // every early return below releases what has been created so far (stream, events, device memory)
     struct Guard {
         upx_plan* p;
@@ -933,8 +994,11 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         p->n_cu = prop.multiProcessorCount;
     read_knobs(p);
+    clock.lap("device properties + knobs");
     HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    clock.lap("hipStreamCreate");
     HIP_TRY(hipMalloc(&p->d_scalar, sizeof(unsigned int)));
+    clock.lap("first hipMalloc");
 #if defined(UPX_EXPERIMENTS)
     if (p->knob_seam_inkernel != 0) {
         HIP_TRY(hipMalloc(&p->d_pair_cnt, (size_t)p->pair_cnt_n * sizeof(int)));
@@ -944,7 +1008,9 @@ int upx_plan_create(upx_plan** out, int device, int n_bands, const int32_t* bloc
     std::vector<size_t> band_win_off;
     std::vector<std::vector<float>> gain_tables;
     if (int rc = plan_select(p, n_bands, block_size, hop, w_analysis, w_synthesis, gain, band_win_off, gain_tables)) return rc;
-    if (int rc = plan_upload(p, w_analysis, w_synthesis, band_win_off, gain_tables)) return rc;
+    clock.lap("plan_select (host)");
+    if (int rc = plan_upload(p, w_analysis, w_synthesis, band_win_off, gain_tables, &clock)) return rc;
+    clock.lap("plan_upload: rest");
     guard.p = nullptr;
     *out = p;
     return UPX_OK;
@@ -1314,8 +1380,9 @@ int zoom_deal_table(upx_plan* p, BandState& s, long long np_xcd, long long per_x
     return UPX_OK;
 }
 
-int zoom_launch(upx_plan* p, BandState& s, const Call& c, const Range& r, const ZoomGeometry& g) {
-    upx::ZoomArgs a;
+// kernel arguments of launch pair L of a group (everything both kernels read)
+int zoom_args(upx_plan* p, BandState& s, const Call& c, const Range& r, const ZoomGeometry& g, const ZoomLaunch& L,
+              upx::ZoomArgs& a, long long* per_xcd_out) {
     std::memset(&a, 0, sizeof a);
     a.in = reinterpret_cast<const upx::cf*>(c.d_stereo);
     a.out_c = c.d_c; a.out_l = c.d_l; a.out_r = c.d_r;
@@ -1332,46 +1399,54 @@ int zoom_launch(upx_plan* p, BandState& s, const Call& c, const Range& r, const 
     a.accumulate = r.first ? 0 : 1;
     const int res_a = zoom_resident(s, true);
     const long long slots = (long long)p->n_cu * res_a;
+    a.stream0 = L.s0_lr; a.ns_lr = L.ns_lr;
+    a.stream0_c = L.s0_c; a.ns_c = L.ns_c;
+    a.f0 = (int)(-1 + 2 * L.pair0);
+    a.pair0 = (int)L.pair0;
+    a.pair_end = (int)L.pair_end;
+    const long long pairs = L.pair_end - L.pair0;
+    a.y = p->d_zoom;
+    a.yc = a.y + (size_t)(2 * pairs) * s.zoom_p;
+    // analysis grid: every resident slot once, 8 x (workgroups per XCD label), see zoom_analysis_program
+    long long per_xcd = (slots + 7) / 8;
+    if (per_xcd > (pairs + 7) / 8) per_xcd = (pairs + 7) / 8;
+    if (per_xcd < 1) per_xcd = 1;
+    a.pairs_per_wg = (int)per_xcd;
+    // its workgroups take the top priority in turn (ZoomArgs) ...
+    a.prio_split = (p->knob_prio_young > 0 && res_a >= 2 && res_a <= 4 && 8 * per_xcd >= (long long)p->n_cu * res_a)
+                       ? p->n_cu : 0;
+    a.prio_rounds = res_a;
+    // ... and the older ones take more pairs
+    a.deal_rows = 0;
+    const long long np_xcd = (pairs + 7) / 8;      // pairs of an XCD's share (zoom_analysis_program)
+    if (a.prio_split > 0 && p->knob_zoom_a_age > 0 && p->knob_zoom_a_age < 40 && np_xcd >= 4 * per_xcd) {
+        const BandState::Deal* deal = nullptr;
+        if (int rc = zoom_deal_table(p, s, np_xcd, per_xcd, res_a, &deal)) return rc;
+        a.deal_rows = deal->rows;
+        a.deal_tab = deal->d_tab;
+    }
+    // ... and so does the synthesis when its streams were cut for that
+    a.prio_split_s = (p->knob_prio_young > 0 && L.once && g.res_s >= 2 && g.res_s <= 4) ? p->n_cu : 0;
+    a.prio_rounds_s = g.res_s;
+    *per_xcd_out = per_xcd;
+    return UPX_OK;
+}
+
+int zoom_launch(upx_plan* p, BandState& s, const Call& c, const Range& r, const ZoomGeometry& g) {
+    upx::ZoomArgs a;
     if (c.timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
     const bool split = c.timing && 2 * (long long)g.launches.size() - 1 <= kMidEvents;
     int n_mid = 0;
     hipEvent_t* mid = s.ring_mid.data() + (size_t)c.slot * kMidEvents;
     int n_launches = 0;
     for (const ZoomLaunch& L : g.launches) {
-        a.stream0 = L.s0_lr; a.ns_lr = L.ns_lr;
-        a.stream0_c = L.s0_c; a.ns_c = L.ns_c;
-        a.f0 = (int)(-1 + 2 * L.pair0);
-        a.pair0 = (int)L.pair0;
-        a.pair_end = (int)L.pair_end;
-        const long long pairs = L.pair_end - L.pair0;
-        a.y = p->d_zoom;
-        a.yc = p->d_zoom + (size_t)(2 * pairs) * s.zoom_p;
-        // analysis grid: every resident slot once, 8 x (workgroups per XCD label), see zoom_analysis_program
-        long long per_xcd = (slots + 7) / 8;
-        if (per_xcd > (pairs + 7) / 8) per_xcd = (pairs + 7) / 8;
-        if (per_xcd < 1) per_xcd = 1;
-        a.pairs_per_wg = (int)per_xcd;
-        // its workgroups take the top priority in turn (ZoomArgs) ...
-        a.prio_split = (p->knob_prio_young > 0 && res_a >= 2 && res_a <= 4 && 8 * per_xcd >= (long long)p->n_cu * res_a)
-                           ? p->n_cu : 0;
-        a.prio_rounds = res_a;
-        // ... and the older ones take more pairs
-        a.deal_rows = 0;
-        const long long np_xcd = (pairs + 7) / 8;      // pairs of an XCD's share (zoom_analysis_program)
-        if (a.prio_split > 0 && p->knob_zoom_a_age > 0 && p->knob_zoom_a_age < 40 && np_xcd >= 4 * per_xcd) {
-            const BandState::Deal* deal = nullptr;
-            if (int rc = zoom_deal_table(p, s, np_xcd, per_xcd, res_a, &deal)) return rc;
-            a.deal_rows = deal->rows;
-            a.deal_tab = deal->d_tab;
-        }
-        // ... and so does the synthesis when its streams were cut for that
-        a.prio_split_s = (p->knob_prio_young > 0 && L.once && g.res_s >= 2 && g.res_s <= 4) ? p->n_cu : 0;
-        a.prio_rounds_s = g.res_s;
+        long long per_xcd = 1;
+        if (int rc = zoom_args(p, s, c, r, g, L, a, &per_xcd)) return rc;
         if (n_launches == 0) {
             s.fill_wg = (int)((L.ns_lr + L.ns_c) * g.groups);
             s.fill_slots = p->n_cu * g.res_s;
             s.fill_wg_a = (int)(8 * per_xcd);
-            s.fill_slots_a = (int)slots;
+            s.fill_slots_a = p->n_cu * zoom_resident(s, true);
         }
         if (split && n_launches > 0) HIP_TRY(hipEventRecord(mid[n_mid++], p->stream));
         if (!c.dry) s.zoom_a->analysis(a, (int)(8 * per_xcd), p->stream);
@@ -1524,7 +1599,7 @@ int fused_launch(upx_plan* p, BandState& s, const Call& c, const Range& r, const
 // upx_plan_reserve's dry run and its warm-up call on a few frames of silence
 struct Reports {
     std::vector<std::tuple<int, int, int, int, int, int>> v;
-    explicit Reports(const upx_plan* p) {
+    void take(const upx_plan* p) {
         for (const auto& s : p->bands) v.emplace_back(s.last_wg, s.last_f, s.fill_wg, s.fill_slots, s.fill_wg_a, s.fill_slots_a);
     }
     void restore(upx_plan* p) const {
@@ -1574,7 +1649,8 @@ int upx_process_device(upx_plan* p, const float* d_stereo, int64_t t_in, int64_t
     }
     const Call c{d_stereo, d_c, d_l, d_r, t_in, own_len, t_out, dry, p->timing && !dry, (int)(p->timed_calls % kTimingSlots)};
     // a dry run reports nothing: the band / launch reports (last_wg, fill_*) keep describing the last REAL call
-    const Reports kept(p);
+    Reports kept;
+    if (dry) kept.take(p);
     for (auto& s : p->bands) {
         s.last_wg = 0;
         if (!c.timing) continue;     // (ev0 / ev1 stay the events of the last TIMED call: upx_plan_band_times_ms reads them)
@@ -1642,7 +1718,8 @@ int upx_plan_reserve(upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out) 
         HIP_TRY(hipMalloc(&tmp, (size_t)n * 5 * sizeof(float)));
         hipError_t e = hipMemsetAsync(tmp, 0, (size_t)n * 2 * sizeof(float), p->stream);
         const bool timing = p->timing;
-        const Reports kept(p);           // the warm-up is not a call of the caller's: it leaves no trace in the reports ...
+        Reports kept;                    // the warm-up is not a call of the caller's: it leaves no trace in the reports ...
+        kept.take(p);
         p->timing = false;               // ... and none in the event rings (timed_once / timed_calls are untouched by untimed calls)
         int rc = e == hipSuccess ? upx_process_device(p, tmp, n, n, tmp + 2 * n, tmp + 3 * n, tmp + 4 * n, n) : UPX_ERR_HIP;
         p->timing = timing;
@@ -2160,11 +2237,6 @@ void wav_chunks(const upx_plan* p, int64_t t_in, int64_t own_len, int64_t t_out,
                       p->knob_wav_kernel_rate, out);
 }
 
-double wall_ms() {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-}
 }   // namespace
 
 int upx_wav_shard_open(upx_plan* p, upx_comm* comm, int in_format, int channels, int64_t t_in, int64_t own_len,
@@ -2271,7 +2343,10 @@ int upx_wav_shard_feed(upx_plan* p, const void* pcm, int64_t n_frames) {
             hipLaunchKernelGGL(upx_decode_kernel, dim3(grid_for(end - up)), dim3(256), 0, st, d_pcm + o, p->wav_fmt, channels,
                                (long long)(end - up), d_st + 2 * up);
             const int64_t owned_end = end < own_len ? end : own_len;   // input peak: owned frames only (main.py:53)
-            if (owned_end > up)
+            if (owned_end > up && p->wav_fmt == UPX_PCM32)      // (exact: on the integers, see upx_absmax_i32_kernel)
+                hipLaunchKernelGGL(upx_absmax_i32_kernel, dim3(grid_reduce(channels * (owned_end - up))), dim3(256), 0, st,
+                                   reinterpret_cast<const int*>(d_pcm + o), (long long)(channels * (owned_end - up)), p->d_wav_peaks);
+            else if (owned_end > up)
                 hipLaunchKernelGGL(upx_absmax_kernel, dim3(grid_reduce(2 * (owned_end - up))), dim3(256), 0, st, d_st + 2 * up,
                                    (long long)(2 * (owned_end - up)), p->d_wav_peaks);
             p->wav_decoded = end;
@@ -2331,7 +2406,8 @@ int upx_wav_shard_seal(upx_plan* p, double* peaks) {
     float pk[4];
     std::memcpy(pk, bits, sizeof pk);
     auto fmax_nan = [](float a, float b) { return (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b); };
-    peaks[0] = (double)pk[0];
+    peaks[0] = p->wav_fmt == UPX_PCM32 ? (double)bits[0] / 2147483648.0 : (double)pk[0];
+    p->wav_in_peak = peaks[0];
     peaks[1] = (double)fmax_nan(fmax_nan(pk[1], pk[2]), pk[3]);
     // what open .. seal cost on the host's clock, and how much of it came after the last sample had landed on the device
     float landed_ms = 0.f;
@@ -2370,7 +2446,7 @@ int upx_wav_shard_peaks(upx_plan* p, double* peaks) {
     for (int i = 0; i < 3; ++i)
         if (int rc = upx_absmax(p, d_pl + (size_t)i * p->wav_tout, p->wav_own, &pk[1 + i])) return rc;
     auto fmax_nan = [](float a, float b) { return (a != a || b != b) ? (a != a ? a : b) : (a > b ? a : b); };
-    peaks[0] = (double)pk[0];
+    peaks[0] = p->wav_fmt == UPX_PCM32 ? p->wav_in_peak : (double)pk[0];   // (32-bit files: the integer peak of the seal)
     peaks[1] = (double)fmax_nan(fmax_nan(pk[1], pk[2]), pk[3]);
     return UPX_OK;
 }
