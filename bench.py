@@ -2,7 +2,7 @@
 """
 bench.py - headline benchmark: stereo Msamples/s upmixed (6 bands, STFT <= 8192).
 
-    python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|default|c4share|batch]
+    python bench.py --gpus N --steps K --warmup W [--workload c1|c2|c3|default|c4share|batch|ov50|ov875|ov60|wide65536]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -27,6 +27,9 @@ A "step" is one pass of the hot path over synthetic stereo already resident in H
            N > 1 ranks: the time-sharded 2 h (at N = 8) signal with the RCCL seam.
   batch    configs[4]: 8 independent 5-min 48 kHz tracks per GPU (64 on 8 GPUs), C3 plan, replicas only (no
            communication); `value` = tracks resident in HBM, the PCIe-inclusive upx_process_tracks rate is in `e2e`.
+  ov50 / ov875 / ov60 / wide65536   arguments the reference accepts outside the BASELINE shapes (any overlap,
+           center_extraction.py:252; any max_block_size, :173): C3's signal and edges at overlap 0.5 / 0.875 / 0.6, and
+           chain_bands([0, 3000]) at the default max_block_size - the perf table of DESIGN.md 7, not BASELINE lines.
 
 The ranks of an N > 1 run meet over upmix_amd.rendezvous (standard-library sockets on the launcher's MASTER_ADDR /
 MASTER_PORT: the 128-byte RCCL id, the barriers and the max-over-ranks of the wall time); this process never imports
@@ -64,7 +67,15 @@ WORKLOADS = {
     "default": (48000, 600,    65536,    "configs[2] signal, reference default plan (max STFT 65536)", None, 32, 2),
     "c4share": (96000, 900,    8192,     "one GPU's share of BASELINE configs[3] (2 h at 96 kHz over 8 GPUs)", None, 32, 2),
     "batch":   (48000, 300,    8192,     "BASELINE configs[4] (8 tracks of 5 min per GPU)",    None, 32, 2),
+    # the argument space the reference accepts beyond the BASELINE shapes (center_extraction.py:56-75, :252, :173-197): C3's
+    # signal and edges at other overlaps, and a wide band at the reference's default max_block_size
+    "ov50":    (48000, 600,    8192,     "configs[2] signal and edges at overlap 0.5 (hop N/2)", None, 32, 2),
+    "ov875":   (48000, 600,    8192,     "configs[2] signal and edges at overlap 0.875 (hop N/8)", None, 32, 2),
+    "ov60":    (48000, 60,     8192,     "60 s of configs[2]'s signal and edges at overlap 0.6 (hop int(0.4 N): the unfused run-time-hop path)", None, 32, 2),
+    "wide65536": (48000, 600,  65536,    "configs[2] signal, chain_bands([0, 3000]) with the reference's default max_block_size: "
+                                         "a 0-3 kHz band at STFT 65536 (pass band too wide for the band-limited path)", [0, 3000], 32, 2),
 }
+OVERLAP = {"ov50": 0.5, "ov875": 0.875, "ov60": 0.6}      # every other workload: 0.75
 TRACKS_PER_GPU = 8
 
 
@@ -127,7 +138,7 @@ def cpu_baseline(workload, target_seconds=15.0):
     from oracle import upmix_oracle as orc
     sr, seconds, _max_stft, _cfg, _edges, _factor, seed = WORKLOADS[workload]
     bands = workload_bands(workload, orc.Band,
-                           lambda e, sr_, m, f: orc.plan_bands(e, 0.75, orc.win_blackman_harris, sr_, max_block_size=m,
+                           lambda e, sr_, m, f: orc.plan_bands(e, OVERLAP.get(workload, 0.75), orc.win_blackman_harris, sr_, max_block_size=m,
                                                                threshold_factor=f))
 
     def run(secs):
@@ -414,7 +425,7 @@ def main():
         args.workload,
         lambda n, ov, lo, hi, sr_, mode, wlo, whi: ux.MultiBandExtractorAccu(n, ov, ux.make_blackman_harris, lo, hi, sr_,
                                                                              mode, wlo, whi, device=local_rank),
-        lambda e, sr_, m, f: ux.chain_bands(e, 0.75, ux.make_blackman_harris, sr_, max_block_size=m, threshold_factor=f,
+        lambda e, sr_, m, f: ux.chain_bands(e, OVERLAP.get(args.workload, 0.75), ux.make_blackman_harris, sr_, max_block_size=m, threshold_factor=f,
                                             verbose=False, device=local_rank))
     plan = ux.DevicePlan(bands, device=local_rank)
     n_bands = len(bands)
@@ -661,7 +672,7 @@ def main():
                 "workload": f"{cfg_name}: " + (f"{TRACKS_PER_GPU} tracks of " if batch else "") +
                             f"{seconds:g} s of {sr // 1000} kHz stereo per GPU, {n_bands} band{'s' if n_bands > 1 else ''} "
                             f"(edges {'/'.join(f'{b.f_low:g}' for b in bands)}/{bands[-1].f_high:g} Hz), STFT {sizes}, "
-                            f"Blackman-Harris 75% WOLA, raised-cosine crossovers XO 0.25, export Ls/C/Rs planes",
+                            f"Blackman-Harris {100 * OVERLAP.get(args.workload, 0.75):g}% WOLA, raised-cosine crossovers XO 0.25, export Ls/C/Rs planes",
                 "name": args.workload,
                 "samples_per_gpu": samples_per_step_rank,
                 "x_realtime": round(total_samples / sr / (elapsed / args.steps), 1),

@@ -191,6 +191,12 @@ int upx_plan_band_times_calls_ms(upx_plan* plan, float* ms, int n_bands, int n_c
    or the band's only kernel. */
 int upx_plan_band_phase_times_sum_ms(upx_plan* plan, float* ms_analysis, float* ms_synthesis, int n_bands, int n_calls);
 int upx_plan_band_phase_kernel_name(upx_plan* plan, int band, int phase, char* name, size_t n);
+/* How the last upx_process_device call cut `band`'s launch group into streams: the first FRAME of every stream (frame j
+   starts at sample j * hop; the first stream starts at frame -1, the pair partner of frame 0) and, last, the end frame.
+   Band-limited groups: the table of the Ls/Rs streams (+ end), then the table of the centre streams (+ end).  Unfused
+   groups: the first emitted block of every chunk.  n_out = entries available; at most `cap` are written.  For tests
+   that aim oracle windows at stream seams, and for reports. */
+int upx_plan_band_stream_starts(upx_plan* plan, int band, int32_t* starts, int32_t cap, int32_t* n_out);
 
 /* Kernel symbol name / launch geometry of a band (for profiles and DESIGN.md). */
 int upx_plan_band_info(upx_plan* plan, int band, int32_t* workgroups, int32_t* threads, int32_t* lds_bytes,

@@ -44,7 +44,16 @@ def test_committed_pmc_summary_names_every_c3_kernel():
 
 
 def test_workload_table():
-    assert set(bench.WORKLOADS) == {"c1", "c2", "c3", "default", "c4share", "batch"}
+    baseline = {"c1", "c2", "c3", "default", "c4share", "batch"}
+    beyond = {"ov50", "ov875", "ov60", "wide65536"}          # the reference's argument space outside the BASELINE shapes
+    assert set(bench.WORKLOADS) == baseline | beyond and set(bench.OVERLAP) == {"ov50", "ov875", "ov60"}
+    from oracle import upmix_oracle as orc
+    ov = lambda w: (lambda e, sr, m, f: orc.plan_bands(e, bench.OVERLAP.get(w, 0.75), orc.win_blackman_harris, sr,  # noqa: E731
+                                                       max_block_size=m, threshold_factor=f))
+    assert [(b.block_size, b.hop_size) for b in bench.workload_bands("ov875", orc.Band, ov("ov875"))][-2:] == [(1024, 128), (256, 32)]
+    assert [(b.block_size, b.hop_size) for b in bench.workload_bands("ov60", orc.Band, ov("ov60"))][-1] == (256, 102)
+    wide = bench.workload_bands("wide65536", orc.Band, ov("wide65536"))
+    assert [(b.block_size, b.f_low, b.f_high) for b in wide] == [(65536, 0, 3000), (512, 3000, 24000.0)]
     sr, seconds, max_stft = bench.WORKLOADS["c3"][:3]
     assert (sr, seconds, max_stft) == (48000, 600, 8192)            # BASELINE configs[2]
     assert bench.WORKLOADS["c4share"][:3] == (96000, 900, 8192)     # 2 h at 96 kHz over 8 GPUs

@@ -48,6 +48,39 @@ def gpu_chain(ux, edges, sr, max_block, tf, mode="raised_cosine", window=None, o
                           threshold_factor=tf, verbose=False)
 
 
+def seam_positions(plan, bands, per_group=3, seed=0):
+    """Sample positions of stream seams of the LAST process_device call, a few per launch group (seeded choice among the
+    interior seams): {group leader: [sample, ...]} (upx_plan_band_stream_starts: frames -> samples through the band's hop)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for b in range(len(bands)):
+        leader, size = plan.band_group(b)
+        if leader != b:
+            continue
+        starts = plan.band_stream_starts(b).astype(np.int64)
+        inner = np.unique(starts[(starts > 0)])[:-1]            # (the last entry is the end frame)
+        assert len(inner) >= per_group, (b, len(inner))
+        pick = rng.choice(inner, size=per_group, replace=False)
+        out[b] = [int(f) * int(bands[b].hop_size) for f in pick]
+    return out
+
+
+def check_oracle_windows(orc, ob, x, out, starts, length, margin, grid):
+    """Oracle restarted at each window start (a multiple of `grid` = 2 hop_max, so every band's frames coincide with the
+    signal's own): behind its fade-in (`margin` = the largest STFT) and before its tail both must agree.  Returns the
+    number of samples compared."""
+    total, checked = len(x), 0
+    for a in starts:
+        a = max(0, min(int(a) // grid * grid, (total - length) // grid * grid))
+        seg = x[a:a + length].astype(np.float64)
+        ref = orc.extract_multi_band(seg[:, 0], seg[:, 1], ob)
+        lo = 0 if a == 0 else margin
+        for got, r in zip(out, ref):
+            close(got[a + lo:a + length - margin], r[lo:length - margin])
+        checked += length - margin - lo
+    return checked
+
+
 def test_golden_single_frame_through_chunk_api(ux):
     z = load_golden("f3_frames.npz")
     for n in (256, 2048, 8192):
@@ -274,6 +307,64 @@ def test_c3_full_size_windows_vs_oracle(ux, orc, c3_full):
     ref = orc.extract_multi_band(seg[:, 0], seg[:, 1], ob)
     for got, r in zip(out, ref):
         close(got[a + 8192:], r[8192:])
+
+
+def test_c3_full_size_one_launch_per_band_windows_at_stream_seams(ux, orc, c3_full):
+    """BASELINE configs[2] as bench.py runs it - the whole 28.8 M samples resident, ONE launch
+    per band group, i.e. the full-chip launch geometry (stream tables, shorter edge streams, XCD dealing) that only long
+    signals select.  Oracle windows at >= 16 seeded offsets, half of them centred on stream seams read off the launch
+    geometry of each group (upx_plan_band_stream_starts), the head and the tail: >= 5 % of the signal, 1e-5 RMS each.  Plus,
+    over ALL samples: the streamed drop-in entry (4 M-sample chunks: other seams) agrees to float32 seam rounding,
+    homogeneity f(2x) = 2 f(x), channel swap."""
+    x, bands, streamed = c3_full
+    total = len(x)
+    ob = orc.plan_bands([0, 30, 120, 480, 1920, 7680], 0.75, orc.win_blackman_harris, 48000, max_block_size=8192)
+    plan = ux.DevicePlan(bands)
+    d_in = plan.alloc(total * 8)
+    d_out = [plan.alloc(total * 4) for _ in range(3)]
+
+    def run(sig):
+        plan.h2d(d_in, sig)
+        plan.process_device(d_in, total, total, d_out[0], d_out[1], d_out[2], total)
+        res = [np.empty(total, np.float32) for _ in range(3)]
+        for o, d in zip(res, d_out):
+            plan.d2h(o, d)
+        return res
+    try:
+        out = run(x)
+        # the geometry under test IS the full-chip one: every group fills (nearly) all its workgroup slots
+        for b in (0, 3, 4, 5):
+            fill = plan.band_fill(b)
+            assert fill["workgroups"] >= 0.9 * fill["slots"], (b, fill)
+        seams = seam_positions(plan, bands, per_group=3, seed=6)
+        assert sorted(seams) == [0, 3, 4, 5]
+        length, margin = 100_000, 8192
+        centred = [p - length // 2 for g in sorted(seams) for p in seams[g]]                 # 12 windows across seams
+        rng = np.random.default_rng(66)
+        anywhere = [int(v) for v in rng.integers(0, total - length, size=8)]                # 8 seeded offsets
+        checked = check_oracle_windows(orc, ob, x, out, [0] + centred + anywhere + [total - length], length, margin, 4096)
+        assert checked >= 0.05 * total, checked
+        # every seam window really holds its seam behind the oracle's fade-in
+        for g in seams:
+            for p_ in seams[g]:
+                a = max(0, (p_ - length // 2) // 4096 * 4096)
+                assert a + margin < p_ < a + length - margin
+        for a, b in zip(out, streamed):
+            assert rms(a.astype(np.float64) - b) < 1e-8 and float(np.max(np.abs(a - b))) < 1e-6
+        # homogeneity over all 28.8 M samples: the mask is scale invariant up to EPS = 1e-12 in its denominators
+        twice = run(x * np.float32(2.0))
+        for a, b in zip(out, twice):
+            assert rms(2.0 * a.astype(np.float64) - b) < 1e-7
+            assert float(np.max(np.abs(2.0 * a.astype(np.float64) - b))) < 1e-5
+        del twice
+        # channel swap over all samples: C stays, Ls and Rs trade places
+        sw = run(np.ascontiguousarray(x[:, ::-1]))
+        assert rms(sw[0].astype(np.float64) - out[0]) < 1e-7
+        assert rms(sw[1].astype(np.float64) - out[2]) < 1e-7 and rms(sw[2].astype(np.float64) - out[1]) < 1e-7
+    finally:
+        for d in [d_in] + d_out:
+            plan.free(d)
+        plan.close()
 
 
 def test_c3_full_size_float64_views_equal_the_float32_call(ux, orc, c3_full):
@@ -1022,6 +1113,15 @@ def test_c4_share_full_size_on_one_device(ux, orc):
         ref = orc.extract_multi_band(seg[:, 0], seg[:, 1], ob)
         for got, r in zip(out, ref):
             close(got[a + 8192:], r[8192:])
+        # windows centred on stream seams of every launch group of THIS call's geometry (the four merged
+        # 8192 bands' band-limited pair, the fused 2048 and 512 launches) + seeded offsets: >= 5 % of the 86.4 M samples
+        seams = seam_positions(plan, bands, per_group=8, seed=4)
+        assert sorted(seams) == [0, 4, 5]
+        length, margin = 100_000, 8192
+        centred = [p_ - length // 2 for g in sorted(seams) for p_ in seams[g]]               # 24 across seams
+        anywhere = [int(v) for v in np.random.default_rng(44).integers(0, total - length, size=30)]
+        checked = check_oracle_windows(orc, ob, x, out, centred + anywhere, length, margin, 4096)
+        assert checked >= 0.05 * total, checked
         # streamed through the host entry (2^22-sample chunks, seams added on the device) == single launch
         streamed = plan.process(x)
         for u, v in zip(out, streamed):

@@ -61,6 +61,7 @@ SIGNATURES = {
     "upx_plan_band_times_calls_ms": (C.c_int, [C.c_void_p, f32p, C.c_int, C.c_int]),
     "upx_plan_band_phase_times_sum_ms": (C.c_int, [C.c_void_p, f32p, f32p, C.c_int, C.c_int]),
     "upx_plan_band_phase_kernel_name": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "upx_plan_band_stream_starts": (C.c_int, [C.c_void_p, C.c_int, i32p, C.c_int32, i32p]),
     "upx_plan_band_info": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, i32p, i32p]),
     "upx_plan_band_fill": (C.c_int, [C.c_void_p, C.c_int, i32p, i32p, i32p, i32p]),
     "upx_plan_band_kernel_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t]),

@@ -410,6 +410,8 @@ struct BandState {
     int n_gain = 1;                     // gain slots per bin (merged bands overlap at crossovers)
     int last_wg = 0, last_f = 0;
     int timed_wg = 0;                   // last_wg of the last TIMED call (ev0 / ev1 belong to it)
+    int last_streams = 0;               // fused launch of the last call: its streams, and whether h_m0 holds their first frames
+    bool last_uneven = false;
     // launch geometry of the last call against the chip: workgroups of the (first) launch of the main kernel / of the
     // band-limited analysis and the workgroup slots the chip holds of them at once (upx_plan_band_fill)
     int fill_wg = 0, fill_slots = 0, fill_wg_a = 0, fill_slots_a = 0;
@@ -1578,6 +1580,8 @@ int fused_launch(upx_plan* p, BandState& s, const Call& c, const Range& r, const
 #endif
     s.last_wg = (int)g.n_wg;
     s.last_f = (int)g.f;
+    s.last_streams = (int)g.n_streams;
+    s.last_uneven = g.uneven;
     s.fill_wg = (int)g.n_wg;
     s.fill_slots = (int)g.slots;
     s.fill_wg_a = s.fill_slots_a = 0;
@@ -2153,6 +2157,25 @@ int upx_plan_band_fill(upx_plan* p, int band, int32_t* workgroups, int32_t* slot
     if (slots) *slots = s.fill_slots;
     if (workgroups_analysis) *workgroups_analysis = s.fill_wg_a;
     if (slots_analysis) *slots_analysis = s.fill_slots_a;
+    return UPX_OK;
+}
+
+int upx_plan_band_stream_starts(upx_plan* p, int band, int32_t* starts, int32_t cap, int32_t* n_out) {
+    if (!p || !n_out || cap < 0 || (cap > 0 && !starts) || band < 0 || band >= (int)p->bands.size())
+        return fail(UPX_ERR_INVALID, "upx_plan_band_stream_starts: bad argument");
+    const BandState& s = p->bands[p->bands[band].group_leader];
+    std::vector<int> v;
+    if (s.last_wg <= 0) {
+        // (the band's group launched nothing in the last call)
+    } else if (s.zoom || (s.kern && s.last_uneven)) {
+        v = s.h_m0;                                   // band-limited: Ls/Rs table (+ end) then centre table (+ end)
+    } else if (s.kern) {
+        for (int i = 0; i <= s.last_streams; ++i) v.push_back(-1 + i * s.last_f);
+    } else {
+        for (int i = 0; i <= s.last_wg; ++i) v.push_back(i * s.last_f);     // unfused: chunks of last_f emitted blocks
+    }
+    *n_out = (int32_t)v.size();
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) starts[i] = v[(size_t)i];
     return UPX_OK;
 }
 

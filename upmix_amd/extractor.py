@@ -226,6 +226,16 @@ class DevicePlan:
         _lib.check(self._lib.upx_plan_band_phase_kernel_name(self.handle, int(band), int(phase), buf, len(buf)))
         return buf.value.decode()
 
+    def band_stream_starts(self, band: int) -> np.ndarray:
+        """First frame of every stream of `band`'s launch group in the last process_device call, then the end frame
+        (band-limited groups: the Ls/Rs table, then the centre table): upx_plan_band_stream_starts."""
+        n = C.c_int32()
+        _lib.check(self._lib.upx_plan_band_stream_starts(self.handle, int(band), None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.int32)
+        _lib.check(self._lib.upx_plan_band_stream_starts(self.handle, int(band), out.ctypes.data_as(_lib.i32p), n.value,
+                                                         C.byref(n)))
+        return out[:n.value]
+
     def band_info(self, band: int) -> dict:
         v = [C.c_int32() for _ in range(4)]
         _lib.check(self._lib.upx_plan_band_info(self.handle, int(band), *(C.byref(i) for i in v)))
