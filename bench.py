@@ -449,12 +449,17 @@ def main():
                 plan.process_device(d, nominal, nominal, d_out[0], d_out[1], d_out[2], nominal)
         calls_per_step = len(d_tracks)
     else:
-        geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
-        # N ranks: one signal of N x `seconds` cut on the shard grid; rank g owns shard g (+ right halo, + spill)
-        shards = geo.plan(nominal * world, world)
-        shard = shards[rank]
+        if world == 1:
+            # one rank: the whole signal, no shard grid needed (hops that share none - overlap 0.6 - run here as well)
+            shard = sharding.Shard(0, 0, nominal, nominal, nominal, True)
+            shards, spill = [shard], 0
+        else:
+            geo = sharding.ShardGeometry([b.block_size for b in bands], [b.hop_size for b in bands])
+            # N ranks: one signal of N x `seconds` cut on the shard grid; rank g owns shard g (+ right halo, + spill)
+            shards = geo.plan(nominal * world, world)
+            shard = shards[rank]
+            spill = geo.spill
         own, t_in, t_out = shard.own_len, shard.t_in, shard.t_out
-        spill = geo.spill if world > 1 else 0
         # synthetic stereo: shard g = seed (2, g) (N=1: seed 2); right halo = head of the next shard
         x = synth(own, seed if world == 1 else (seed, rank))
         if t_in > own:

@@ -158,6 +158,51 @@ def test_arbitrary_overlap_unfused_path(ux, orc, monkeypatch):
     plan.close()
 
 
+def test_unfused_wide_bands_at_large_stft_one_pass_tail(ux, orc, monkeypatch):
+    """Round 6: wide bands at STFT 32 768 / 65 536 - e.g. chain_bands([0, 3000]) with the reference's
+    default max_block_size - cannot take the band-limited path and run the unfused pipeline.  Its last two kernels (step 2 of
+    the inverse transforms, then the gather overlap-add) are ONE pass now for hop N/2, N/4, N/8 (upx_big_tail_kernel:
+    the overlap-add state of a column in registers).  Against the oracle, and against the two-kernel route of rounds 1-5
+    (UPX_BIG_TAIL=0): the same float32 additions in the same order.  Small chunks (UPX_BIG_CHUNK_LOG2) put several chunks
+    and ragged ranges of emitted blocks into a short signal."""
+    x = orc.synthetic_stereo(900_000, 15)
+    cases = [
+        ("default wide", dict(edges=[0, 3000], overlap=0.75, max_block=65536, mode="raised_cosine")),
+        ("K = 2", dict(edges=[0, 2500], overlap=0.5, max_block=32768, mode="hard_zero")),
+        ("K = 8", dict(edges=[0, 2000], overlap=0.875, max_block=65536, mode="raised_cosine")),
+    ]
+    for chunk_log2 in ("24", "20"):
+        monkeypatch.setenv("UPX_BIG_CHUNK_LOG2", chunk_log2)
+        for name, c in cases:
+            ob = orc.plan_bands(c["edges"], c["overlap"], orc.win_blackman_harris, 48000, c["mode"], max_block_size=c["max_block"])
+            ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+            outs = {}
+            for tail in ("1", "0"):
+                monkeypatch.setenv("UPX_BIG_TAIL", tail)
+                bands = gpu_chain(ux, c["edges"], 48000, c["max_block"], 32, mode=c["mode"], overlap=c["overlap"])
+                assert bands[0].block_size == c["max_block"]
+                plan = ux.DevicePlan(bands)
+                assert "unfused" in plan.band_kernel_name(0), name
+                outs[tail] = plan.process(x)
+                plan.close()
+                for got, r in zip(outs[tail], ref):
+                    close(got, r)
+            for a, b in zip(outs["1"], outs["0"]):
+                assert np.array_equal(a, b), (name, chunk_log2, rms(a.astype(np.float64) - b))
+    # two merged 65 536 bands (one transform, per-bin gain list) whose pass bands are too wide for the band-limited path
+    monkeypatch.setenv("UPX_BIG_CHUNK_LOG2", "24")
+    monkeypatch.delenv("UPX_BIG_TAIL")
+    gb = [ux.MultiBandExtractorAccu(65536, 0.75, ux.make_blackman_harris, lo, hi, 48000, "raised_cosine", wl, wh)
+          for lo, hi, wl, wh in ((0.0, 900.0, 0.0, 225.0), (900.0, 4000.0, 225.0, 1000.0))]
+    ob = [orc.Band(65536, 0.75, lo, hi, 48000, "raised_cosine", wl, wh) for lo, hi, wl, wh in ((0.0, 900.0, 0.0, 225.0), (900.0, 4000.0, 225.0, 1000.0))]
+    ref = orc.extract_multi_band(x[:, 0].astype(np.float64), x[:, 1].astype(np.float64), ob)
+    plan = ux.DevicePlan(gb)
+    assert plan.band_group(0) == (0, 2) and "unfused" in plan.band_kernel_name(0)
+    for got, r in zip(plan.process(x), ref):
+        close(got, r)
+    plan.close()
+
+
 def test_golden_multi_band(ux):
     z = load_golden("f5_multiband.npz")
     plans = {

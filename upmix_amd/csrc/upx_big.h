@@ -46,6 +46,7 @@ struct BigArgs {
     int ch;                // frames in the chunk (even)
     int m0, m1;            // hop-blocks this chunk emits: [m0, m1)
     int accumulate;
+    int tail;              // 1: big_tail (step 2 + overlap-add in one pass) where it applies; 0: big_step2_inv + big_ola
 };
 
 template <int LOG2N>
@@ -532,6 +533,86 @@ UPX_HD void big_ola(const BigArgs& a, long long gid) {
         a.out_c[n] = acc_c;
         a.out_l[n] = acc_l;
         a.out_r[n] = acc_r;
+    }
+}
+
+// ---- step 2 and the overlap-add in ONE pass (round 6) ------------------------------------------------------------
+// For hop = N/2, N/4, N/8 a hop is a whole number HS = 16 / K of N2-sample slots, so the last step of the inverse
+// transforms (twiddle, radix-16 over k1: sample n1 N2 + n2 of a frame comes out of column n2) can keep the running
+// overlap-add sum of its column in registers exactly like a fused stream does: thread = (range of RB emitted blocks,
+// column n2) walks the frames that feed its blocks in increasing j - slot s of the three 16-slot accumulators holds the
+// sum at sample (j HS + s) N2 + n2 -, emits the HS finished slots of block j and shifts.  y and yc are read ONCE (+ the
+// K - 1 frames in front of a range) and never written back: big_step2_inv's read + write of both and big_ola's gather
+// read are gone - 3 of the 5.3 passes over the scratch per chunk.  Same float32 additions in the same order as big_ola
+// (from 0.0f, increasing j).  Consecutive n2 read and write consecutive addresses.
+template <class B, int K>
+UPX_HD void big_tail(const BigArgs& a, int rb, long long gid) {
+    constexpr int N = B::N, N2 = B::N2, HS = 16 / K;
+    static_assert(B::N1 == 16 && (K == 2 || K == 4 || K == 8), "hop = N/2, N/4, N/8 of a four-step frame");
+    const int n2 = (int)(gid % N2);
+    const long long m_a = (long long)a.m0 + (gid / N2) * rb;
+    if (m_a >= a.m1) return;
+    const long long m_b = m_a + rb < a.m1 ? m_a + rb : a.m1;
+    float acc_c[16], acc_l[16], acc_r[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc_c[s] = acc_l[s] = acc_r[s] = 0.f;
+    cf cc[16];                       // the pair's centre signals: frame jj even -> .y, odd -> .x (swapped outputs)
+    int pair_have = -1;
+    long long j = m_a - (K - 1);
+    if (j < a.j_lo) j = a.j_lo;      // (frames in front of the first one do not exist: their slots stay 0)
+    // accumulator slot 0 stands for block j of this first frame; earlier blocks of the range (m_a < j never happens:
+    // j <= m_a) need no skipping
+    for (; j < m_b; ++j) {
+        if (j < a.j_hi) {
+            const int jj = (int)(j - a.j0);
+            const cf* p = a.y + (size_t)jj * N;
+            // the twiddle column and the window column are the same for every frame: fetched per frame all the same (L2
+            // hits) - hoisted out of the loop they are 46 registers and the kernel spills at two waves per SIMD
+            const auto* tw = opaque(a.tw_n);
+            const auto* ws = opaque(a.w_s);
+            cf v[16];
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) v[k1] = k1 == 0 ? p[n2] : cmul(p[k1 * N2 + n2], tw[k1 * N2 + n2]);
+            Dft<16>::run(v);
+            if ((jj >> 1) != pair_have) {
+                pair_have = jj >> 1;
+                const cf* q = a.yc + (size_t)pair_have * N;
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) cc[k1] = k1 == 0 ? q[n2] : cmul(q[k1 * N2 + n2], tw[k1 * N2 + n2]);
+                Dft<16>::run(cc);
+            }
+            const bool even = (jj & 1) == 0;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const float w = ws[n1 * N2 + n2];
+                acc_l[n1] += v[n1].y * w;                 // swapped outputs: Re = .y, Im = .x
+                acc_r[n1] += v[n1].x * w;
+                acc_c[n1] += (even ? cc[n1].y : cc[n1].x) * w;
+            }
+        }
+        if (j >= m_a) {
+#pragma unroll
+            for (int s = 0; s < HS; ++s) {
+                const long long n = (j * HS + s) * N2 + n2;
+                if (n < a.t_out) {
+                    if (a.accumulate) {
+                        a.out_c[n] += acc_c[s];
+                        a.out_l[n] += acc_l[s];
+                        a.out_r[n] += acc_r[s];
+                    } else {
+                        a.out_c[n] = acc_c[s];
+                        a.out_l[n] = acc_l[s];
+                        a.out_r[n] = acc_r[s];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            acc_c[s] = s + HS < 16 ? acc_c[s + HS] : 0.f;
+            acc_l[s] = s + HS < 16 ? acc_l[s + HS] : 0.f;
+            acc_r[s] = s + HS < 16 ? acc_r[s + HS] : 0.f;
+        }
     }
 }
 

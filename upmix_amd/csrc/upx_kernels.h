@@ -155,6 +155,11 @@ template <class B>
 __global__ __launch_bounds__(256) void upx_big_ola_kernel(upx::BigArgs a) {
     upx::big_ola<B>(a, (long long)blockIdx.x * 256 + threadIdx.x);
 }
+// step 2 + overlap-add in one pass (hop = N/K, K = 2, 4, 8; frames of sixteen rows that pass through the scratch)
+template <class B, int K>
+__global__ __launch_bounds__(256, 2) void upx_big_tail_kernel(upx::BigArgs a, int rb) {
+    if constexpr (B::N1 == 16) upx::big_tail<B, K>(a, rb, (long long)blockIdx.x * 256 + threadIdx.x);
+}
 
 // ---- band-limited bands: pruned analysis / residue-stream synthesis (upx_zoom.h) --------------------------
 // Z::WPE_A / WPE_S = waves per SIMD the register allocator leaves room for (4 -> 128 VGPRs, 3 -> 168): what the LDS
@@ -224,6 +229,7 @@ struct BigImpl {
     // N = 16 384: the sixteen 1024-point rows of a frame fit one workgroup's LDS (149 KB): whole-frame variant
     static constexpr int kMidRows = (B::N1 == 16 && 16 * Row::LANES == B::N2 && (16 * Row::PITCH + Row::TW_CF) * 8 <= 160 * 1024) ? 16 : 2;
     static constexpr int kMidLds = (kMidRows * Row::PITCH + Row::TW_CF) * (int)sizeof(upx::cf);
+    static constexpr int kTailBlocks = 8;     // emitted blocks per thread of upx_big_tail_kernel
     static unsigned blocks(long long n) { return (unsigned)((n + 255) / 256); }
     static unsigned row_wgs(int rows) { return (unsigned)((rows + Row::G - 1) / Row::G); }
     static void rows(upx::cf* buf, const upx::cf* tw, int n_rows, hipStream_t st) {
@@ -245,6 +251,18 @@ struct BigImpl {
             hipLaunchKernelGGL(upx_big_frame_kernel<B>, dim3(row_wgs(ch)), dim3(Row::WG), kRowLds, st, a);
             hipLaunchKernelGGL(upx_big_mask_kernel<B>, dim3(blocks(upx::big_mask_threads<B>(ch / 2))), dim3(256), 0, st, a);
             rows(a.y, a.tw_rows, inv_frames * B::N1, st);
+        }
+        if constexpr (B::N1 == 16 && kMidRows == 2) {
+            if (a.tail && a.hop * a.kf == B::N && (a.kf == 2 || a.kf == 4 || a.kf == 8)) {
+                // ranges of kTailBlocks emitted blocks: 2^24 / N frames per chunk make ~32 ranges x N2 columns (>= 8 waves
+                // per CU); the K - 1 frames in front of a range are read by two ranges
+                const int rb = kTailBlocks;
+                const long long threads = (long long)((a.m1 - a.m0 + rb - 1) / rb) * B::N2;
+                if (a.kf == 2) hipLaunchKernelGGL((upx_big_tail_kernel<B, 2>), dim3(blocks(threads)), dim3(256), 0, st, a, rb);
+                else if (a.kf == 4) hipLaunchKernelGGL((upx_big_tail_kernel<B, 4>), dim3(blocks(threads)), dim3(256), 0, st, a, rb);
+                else hipLaunchKernelGGL((upx_big_tail_kernel<B, 8>), dim3(blocks(threads)), dim3(256), 0, st, a, rb);
+                return;
+            }
         }
         if (B::N1 == 16 && kMidRows == 2)
             hipLaunchKernelGGL(upx_big_step2_inv_kernel<B>, dim3(blocks((long long)inv_frames * B::N2)), dim3(256), 0, st, a.y, a.tw_n, inv_frames);

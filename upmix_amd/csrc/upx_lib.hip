@@ -447,6 +447,7 @@ struct upx_plan {
     int knob_zoom_a_age = 8;                // UPX_ZOOM_A_AGE: % by which each later dispatch round of the band-limited analysis runs slower (0 = equal shares)
     int knob_zoom_edge_percent = 76;        // UPX_ZOOM_EDGE_PERCENT: length of the first / last synthesis stream of a signal (100 = like the others)
     double knob_zoom_c_cost = 0.55;         // UPX_ZOOM_C_COST: what a frame costs a centre stream, in Ls/Rs frames (stream length ratio)
+    int knob_big_tail = 1;                  // UPX_BIG_TAIL: unfused frames of sixteen rows (N = 32 768, 65 536) at hop N/2, N/4, N/8 run step 2 + overlap-add as ONE pass (0: big_step2_inv + big_ola, the route of rounds 1-5)
     int knob_seam_vec = 1;                  // UPX_SEAM_VEC: stream-seam passes with 16-byte accesses where alignment allows (0: scalar passes)
 #if defined(UPX_EXPERIMENTS)
     // experiment builds only (round 4 / 5 A/Bs, all rejected: docs/LOG.md).  The product library launches the groups in list
@@ -679,6 +680,7 @@ void read_knobs(upx_plan* p) {
     if (const char* e = knob("UPX_MIN_STREAM_FRAMES")) p->knob_min_stream_frames = std::atoi(e);
     if (const char* e = knob("UPX_WAV_CHUNK")) p->knob_wav_chunk = std::atoll(e);
     if (const char* e = knob("UPX_SEAM_VEC")) p->knob_seam_vec = std::atoi(e);
+    if (const char* e = knob("UPX_BIG_TAIL")) p->knob_big_tail = std::atoi(e);
     if (const char* e = knob("UPX_WAV_UNIFORM")) p->knob_wav_uniform = std::atoi(e);
     if (const char* e = knob("UPX_WAV_KERNEL_RATE")) p->knob_wav_kernel_rate = std::atof(e);
     if (const char* e = knob("UPX_ZOOM_ONCE")) p->knob_zoom_once = std::atoi(e);
@@ -1214,6 +1216,7 @@ int launch_unfused(upx_plan* p, BandState& s, const Call& c, const Range& r) {
     a.hop = s.hop; a.kf = s.k;
     a.j_lo = 0; a.j_hi = (int)r.j_hi; a.ch = ch;
     a.accumulate = r.first ? 0 : 1;
+    a.tail = p->knob_big_tail;
     if (c.timing) HIP_TRY(hipEventRecord(s.ev0, p->stream));
     int n_chunks = 0;
     for (long long m0 = 0; m0 < r.m_hi; m0 += emit, ++n_chunks) {
