@@ -256,7 +256,7 @@ struct BigImpl {
             if (a.tail && a.hop * a.kf == B::N && (a.kf == 2 || a.kf == 4 || a.kf == 8)) {
                 // ranges of kTailBlocks emitted blocks: 2^24 / N frames per chunk make ~32 ranges x N2 columns (>= 8 waves
                 // per CU); the K - 1 frames in front of a range are read by two ranges
-                const int rb = kTailBlocks;
+                const int rb = a.tail > 1 ? a.tail : kTailBlocks;    // (UPX_BIG_TAIL = n > 1: n blocks per range, for sweeps)
                 const long long threads = (long long)((a.m1 - a.m0 + rb - 1) / rb) * B::N2;
                 if (a.kf == 2) hipLaunchKernelGGL((upx_big_tail_kernel<B, 2>), dim3(blocks(threads)), dim3(256), 0, st, a, rb);
                 else if (a.kf == 4) hipLaunchKernelGGL((upx_big_tail_kernel<B, 4>), dim3(blocks(threads)), dim3(256), 0, st, a, rb);
