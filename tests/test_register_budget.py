@@ -101,3 +101,59 @@ def test_no_selected_kernel_uses_agprs_or_dynamic_stack(resources):
     for name in list(FUSED) + list(ZOOM):
         r = resources[bench.canonical_kernel_name(name)]
         assert r.get("agprs", 0) == 0, (name, r)
+
+
+# The argument space beyond the BASELINE shapes (bench.py --workload ov50 | ov875 | wide65536): what those plans
+# select, held to the same kind of budget.  Scratch where listed sits in the signal-EDGE bodies only - the interior loops of
+# these kernels hold none (scripts/scratch_in_loops.py; profiles/r06_hop8_scratch_location.txt).
+BEYOND = {
+    "upx_band_kernel<upx::Cfg<10, 2, 16>, 2, false>": (2, 0, "ov50"),
+    "upx_band_kernel<upx::Cfg<8, 2, 16>, 2, false>": (2, 0, "ov50"),
+    "upx_band_kernel<upx::Cfg<10, 8, 16>, 2, false>": (2, 0, "ov875"),
+    "upx_band_kernel<upx::Cfg<8, 8, 16>, 2, false>": (2, 0, "ov875"),
+    "upx_zoom_analysis_kernel<upx::ZoomCfg<8, 16, 2>>": (3, 0, "ov50"),
+    "upx_zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 2>>": (3, 44, "ov50 (edge body)"),
+    "upx_zoom_analysis_kernel<upx::ZoomCfg<9, 8, 2>>": (3, 0, "ov50"),
+    "upx_zoom_synthesis_kernel<upx::ZoomCfg<9, 8, 2>>": (3, 12, "ov50 (edge body)"),
+    "upx_zoom_analysis_kernel<upx::ZoomCfg<8, 16, 8>>": (3, 0, "ov875"),
+    "upx_zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 8>>": (3, 0, "ov875"),
+    "upx_zoom_analysis_kernel<upx::ZoomCfg<9, 8, 8>>": (3, 0, "ov875"),
+    "upx_zoom_synthesis_kernel<upx::ZoomCfg<9, 8, 8>>": (3, 0, "ov875"),
+    "upx_big_tail_kernel<upx::BigCfg<16>, 4>": (2, 0, "wide65536: step 2 + overlap-add in one pass"),
+    "upx_big_tail_kernel<upx::BigCfg<16>, 2>": (2, 0, "wide bands at hop N/2"),
+    "upx_big_tail_kernel<upx::BigCfg<16>, 8>": (2, 0, "wide bands at hop N/8"),
+    "upx_big_tail_kernel<upx::BigCfg<15>, 4>": (2, 0, "STFT 32768"),
+}
+# every kernel of the library that carries scratch at all, with its ceiling in bytes per lane: a new name here, or a
+# larger number, is a regression to look at (where it sits: scripts/scratch_in_loops.py)
+KNOWN_SCRATCH = {
+    "upx_band_kernel<upx::Cfg<10, 8, 16>, 2>": 16, "upx_band_kernel<upx::Cfg<11, 4, 16>, 2>": 12,
+    "upx_band_kernel<upx::Cfg<11, 8, 16>, 2, false>": 36, "upx_band_kernel<upx::Cfg<11, 8, 16>, 2>": 68,
+    "upx_band_kernel<upx::Cfg<8, 8, 16>, 2>": 12, "upx_band_kernel<upx::WideCfg<12, 4>, 2, false>": 36,
+    "upx_band_kernel<upx::WideCfg<12, 8>, 2, false>": 44, "upx_band_kernel<upx::WideCfg<12, 8>, 2>": 12,
+    "upx_band_kernel<upx::WideCfg<13, 8>, 2, false>": 12, "upx_band_kernel<upx::WideCfg<13, 8>, 2>": 12,
+    "upx_big_mid_kernel<upx::BigCfg<15>, 2>": 120, "upx_big_mid_kernel<upx::BigCfg<16>, 2>": 120,
+    "upx_zoom_synthesis_kernel<upx::ZoomCfg<10, 16, 2>>": 12, "upx_zoom_synthesis_kernel<upx::ZoomCfg<10, 16, 4>>": 8,
+    "upx_zoom_synthesis_kernel<upx::ZoomCfg<8, 16, 2>>": 44, "upx_zoom_synthesis_kernel<upx::ZoomCfg<8, 8, 2>>": 60,
+    "upx_zoom_synthesis_kernel<upx::ZoomCfg<9, 8, 2>>": 12,
+}
+
+
+@pytest.mark.parametrize("name", sorted(BEYOND))
+def test_kernels_of_the_argument_space_workloads(resources, name):
+    occ, scratch, where = BEYOND[name]
+    r = resources[bench.canonical_kernel_name(name)]
+    assert r["occupancy_waves_per_simd"] == occ, (name, where, r)
+    assert r["vgprs"] + r.get("agprs", 0) <= 512 // occ and r.get("agprs", 0) == 0, (name, r)
+    assert r["scratch_bytes_per_lane"] <= scratch, (name, where, r)
+
+
+def test_every_kernel_with_scratch_is_known(resources):
+    known = {bench.canonical_kernel_name(k): v for k, v in KNOWN_SCRATCH.items()}
+    for name, r in resources.items():
+        if r["scratch_bytes_per_lane"] > 0:
+            assert name in known, (name, r["scratch_bytes_per_lane"])
+            assert r["scratch_bytes_per_lane"] <= known[name], (name, r["scratch_bytes_per_lane"], known[name])
+    # ... and none of them is a kernel a BASELINE plan selects (except C2's two-gain-slot wide flavour, budgeted above)
+    baseline = {bench.canonical_kernel_name(k) for k in list(FUSED) + list(ZOOM)}
+    assert not (set(known) & baseline) - {bench.canonical_kernel_name("upx_band_kernel<upx::WideCfg<12, 4>, 2>")}
