@@ -1,6 +1,9 @@
 #!/bin/bash
 # A/B of kernel builds inside ONE gpurun call (boxes differ by +-2 %): scripts/ab.sh <workload> <lib.so>...
 # Each library runs the bench twice, interleaved; prints ms per step and per kernel.
+# (round 6: the library reads UPX_* knobs only with UPX_TUNING=1; the round-4/5 experiment knobs this script drives also need an
+# experiment build: __graft_entry__.build_hip(extra_flags=["-DUPX_EXPERIMENTS"], lib="exp/ab/experiments.so") + UPMIX_HIP_LIB)
+export UPX_TUNING=1
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/ab
 wl=$1; shift

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer check on a GPU box: parity of each kernel size vs the oracle + C3 timing per band."""
 import os
+os.environ.setdefault("UPX_TUNING", "1")   # round 6: the library reads its UPX_* knobs only in a process that opts in
 import sys
 import time
 

@@ -1,5 +1,8 @@
 #!/bin/bash
 # launch order experiment (UPX_FIRST_BAND): which launch writes the planes instead of read-modify-writing them
+# (round 6: the library reads UPX_* knobs only with UPX_TUNING=1; the round-4/5 experiment knobs this script drives also need an
+# experiment build: __graft_entry__.build_hip(extra_flags=["-DUPX_EXPERIMENTS"], lib="exp/ab/experiments.so") + UPMIX_HIP_LIB)
+export UPX_TUNING=1
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/r4b; mkdir -p $O
 for rep in 1 2; do

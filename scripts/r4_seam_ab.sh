@@ -1,4 +1,7 @@
 #!/bin/bash
+# (round 6: the library reads UPX_* knobs only with UPX_TUNING=1; the round-4/5 experiment knobs this script drives also need an
+# experiment build: __graft_entry__.build_hip(extra_flags=["-DUPX_EXPERIMENTS"], lib="exp/ab/experiments.so") + UPMIX_HIP_LIB)
+export UPX_TUNING=1
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/r4seam; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; rc=$?; echo "tests rc $rc"; tail -3 $O/tests.log

@@ -1,4 +1,7 @@
 #!/bin/bash
+# (round 6: the library reads UPX_* knobs only with UPX_TUNING=1; the round-4/5 experiment knobs this script drives also need an
+# experiment build: __graft_entry__.build_hip(extra_flags=["-DUPX_EXPERIMENTS"], lib="exp/ab/experiments.so") + UPMIX_HIP_LIB)
+export UPX_TUNING=1
 cd "${GRAFT_REPO_ROOT:-.}"
 O=gpurun_out/r4e; mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_multi_gpu.py -m gpu -x -q -k "wav or stream or sharded or file" > $O/tests.log 2>&1; rc=$?; echo "tests rc $rc"; tail -3 $O/tests.log

@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round 5: A/B of the dual-stream experiment kernels (UPX_DUAL) and the scratch size of the band-limited path inside ONE
 # gpurun call.  Prints ms per step and per launch group.
+# (round 6: the library reads UPX_* knobs only with UPX_TUNING=1; the round-4/5 experiment knobs this script drives also need an
+# experiment build: __graft_entry__.build_hip(extra_flags=["-DUPX_EXPERIMENTS"], lib="exp/ab/experiments.so") + UPMIX_HIP_LIB)
+export UPX_TUNING=1
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/r5b
 run() {   # tag, env...

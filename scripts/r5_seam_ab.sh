@@ -1,5 +1,8 @@
 #!/bin/bash
 # Round 5: stream seams inside the fused launch (UPX_SEAM_INKERNEL: 0 never, 1 always, 2 when the launch does not fill the chip)
+# (round 6: the library reads UPX_* knobs only with UPX_TUNING=1; the round-4/5 experiment knobs this script drives also need an
+# experiment build: __graft_entry__.build_hip(extra_flags=["-DUPX_EXPERIMENTS"], lib="exp/ab/experiments.so") + UPMIX_HIP_LIB)
+export UPX_TUNING=1
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out/r5f
 UPX_SEAM_INKERNEL=1 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r5f/pytest_inkernel1.txt 2>&1; echo "pytest (UPX_SEAM_INKERNEL=1) rc=$?"; tail -3 gpurun_out/r5f/pytest_inkernel1.txt

@@ -1,5 +1,8 @@
 #!/bin/bash
 # Sweep of an experiment build's environment knobs inside ONE gpurun call: scripts/sweep_env.sh <lib.so> <workload> "A=1 B=2" "A=2 B=2" ...
+# (round 6: the library reads UPX_* knobs only with UPX_TUNING=1; the round-4/5 experiment knobs this script drives also need an
+# experiment build: __graft_entry__.build_hip(extra_flags=["-DUPX_EXPERIMENTS"], lib="exp/ab/experiments.so") + UPMIX_HIP_LIB)
+export UPX_TUNING=1
 cd "${GRAFT_REPO_ROOT:-.}"
 lib=$1; wl=$2; shift 2
 mkdir -p gpurun_out/sweep

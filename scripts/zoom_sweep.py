@@ -3,6 +3,7 @@
 Usage: python scripts/zoom_sweep.py "<ENV=VAL ENV=VAL>" ...   (each argument = one configuration; "" = defaults)
        UPX_SWEEP_PLAN=c3|c4|default selects the workload."""
 import os
+os.environ.setdefault("UPX_TUNING", "1")   # round 6: the library reads its UPX_* knobs only in a process that opts in
 import subprocess
 import sys
 
